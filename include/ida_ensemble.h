@@ -1,0 +1,79 @@
+/* ida_ensemble.h -- C entry points of libidaens.so: the host-side BDF stepper for an ensemble of independent IVPs.
+ *
+ * This is the caller side of the drop-in boundary: it plays the role of the reference's `Ida` object
+ * (src/lib.rs:89-244) -- `Ida::new`, `Ida::solve`, the getters of src/ida_io.rs -- for `batch` systems at once, and
+ * reaches the device only through include/ida_hip.h. In the reference this layer is Rust and stays Rust; no Rust
+ * toolchain exists in the build image, so the stand-in is C++ with the reference's structure (IdaNLProblem /
+ * IdaLProblem / Newton state per system, same names, same error behaviour). All scalar control logic (set_coeffs,
+ * lsetup decision, idaNlsConvTest incl. powf, test_error decisions, handle_n_flag, complete_step order/step selection,
+ * stop tests, get_solution coefficients) runs on the host with the platform libm, per system, exactly as
+ * src/lib.rs / src/impl_*.rs do; vectors never leave the device.
+ */
+#ifndef IDA_ENSEMBLE_H
+#define IDA_ENSEMBLE_H
+
+#include <stdint.h>
+
+#include "ida_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct idaens idaens;
+
+/* IdaTask (src/lib.rs:50-54) */
+enum { IDAENS_NORMAL = 0, IDAENS_ONE_STEP = 1 };
+/* per-system return of solve: IdaSolveStatus (src/lib.rs:56-62) >= 0, IdaError (src/error.rs) < 0 */
+enum {
+    IDAENS_SUCCESS = 0,
+    IDAENS_TSTOP_RETURN = 1,
+    IDAENS_ROOT_RETURN = 2,
+    IDAENS_UNFINISHED = 99, /* round limit hit before the system reached tout (bench mode only) */
+    IDAENS_TOO_MUCH_WORK = -1,
+    IDAENS_TOO_MUCH_ACC = -2,
+    IDAENS_ERR_FAIL = -3,
+    IDAENS_CONV_FAIL = -4,
+    IDAENS_LSETUP_FAIL = -6,
+    IDAENS_ILL_INPUT = -22,
+    IDAENS_BAD_T = -26
+};
+
+/* Ida::new(problem, yy0, yp0, tol_control) for every system of ctx (src/lib.rs:278-405); ctx must already hold the
+ * tolerances and problem data. hYY0, hYP0: [batch][n]. */
+int idaens_create(idaens** e, idahip_ctx* ctx, const double* hYY0, const double* hYP0);
+int idaens_destroy(idaens* e);
+const char* idaens_last_error(const idaens* e);
+
+/* optional inputs (the reference has defaults only, src/lib.rs:309-321; setters follow C IDA's names) */
+int idaens_set_max_num_steps(idaens* e, long mxstep); /* 0 = unlimited; default 500 (MXSTEP_DEFAULT) */
+int idaens_set_max_ord(idaens* e, int maxord);        /* 1..5, default 5 */
+
+/* Ida::solve(tout, &mut tret, itask) for every system (src/impl_solve.rs:69-376). hTret/hStatus: [batch].
+ * max_rounds > 0 bounds the number of lock-step attempt rounds (systems still stepping report IDAENS_UNFINISHED and
+ * resume on the next call with the same tout). Returns 0, or < 0 on a device/ABI failure. */
+int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds);
+
+/* getters (src/ida_io.rs:11-117), arrays of length batch */
+enum {
+    IDAENS_C_NST = 0, IDAENS_C_NRE = 1, IDAENS_C_NJE = 2, IDAENS_C_NSETUPS = 3, IDAENS_C_NNI = 4, IDAENS_C_NETF = 5,
+    IDAENS_C_NCFN = 6, IDAENS_C_NATTEMPTS = 7, IDAENS_C_NLS_NCONVFAILS = 8, IDAENS_C_KUSED = 9, IDAENS_C_KK = 10
+};
+int idaens_get_counter(const idaens* e, int which, int64_t* out);
+enum { IDAENS_R_TN = 0, IDAENS_R_HUSED = 1, IDAENS_R_HH = 2, IDAENS_R_H0U = 3, IDAENS_R_TOLSF = 4 };
+int idaens_get_real(const idaens* e, int which, double* out);
+/* get_yy / get_yp: [batch][n] */
+int idaens_get_yy(idaens* e, double* hYY);
+int idaens_get_yp(idaens* e, double* hYP);
+/* totals over the ensemble since creation */
+int64_t idaens_total_newton_iters(const idaens* e);
+int64_t idaens_total_rounds(const idaens* e);
+/* per-accepted-step trace of one system (tn, hused, kused), for parity tests; enable before solving */
+int idaens_trace_system(idaens* e, int sys);
+long idaens_trace_len(const idaens* e);
+int idaens_trace_get(const idaens* e, double* out /* [len][3] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

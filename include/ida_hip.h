@@ -1,0 +1,144 @@
+/* ida_hip.h -- C ABI of libidahip.so: the MI355X (gfx950) implementation of rust-ida's BDF/Newton hot path for an
+ * ensemble (batch) of independent IVPs.
+ *
+ * Every entry point is the batched generalisation of one trait method / function of the reference
+ * (jondo2010/rust-ida, paths relative to the reference root); with batch = 1 and nsys = 1 a call reproduces the
+ * reference call exactly. A Rust `impl LSolver / NLSolver / NLProblem / IdaProblem` forwards to these symbols
+ * (binding sketch: INTEGRATION.md).
+ *
+ * Conventions
+ *   - all floating point is fp64; no FMA contraction anywhere (the reference is plain Rust arithmetic);
+ *   - matrices are column-major per system, A(i,j) = a[j*n + i] (nalgebra layout of crates/linear/src/dense.rs);
+ *   - "h" pointers are host memory, borrowed for the duration of the call; "d" pointers are device memory;
+ *   - hIdx[0..nsys) lists the systems a call acts on (the reference acts on one `Ida` at a time); per-call scalar
+ *     arguments (hTn, hCj, ...) are indexed by list position, not by system id;
+ *   - return value: 0 ok; > 0 recoverable (some listed system flagged, see the per-system output); < 0 fatal
+ *     (bad argument, HIP error) -- the taxonomy documented at crates/nonlinear/src/traits.rs:17-22;
+ *   - nothing panics, throws or aborts across this boundary; idahip_last_error() describes the last failure;
+ *   - a ctx is not thread-safe (all reference methods take &mut self); different ctxs may be driven concurrently.
+ */
+#ifndef IDA_HIP_H
+#define IDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct idahip_ctx idahip_ctx; /* opaque; owns all device state of one ensemble on one device */
+
+/* User problems shipped as device code (src/traits.rs:12-70 `Residual`/`Jacobian`; H5 in SURVEY.md: a generic Rust
+ * closure cannot cross an FFI into device code, so the set is closed and selected by enum). */
+typedef enum {
+    IDAHIP_ROBERTS = 0,      /* src/sample_problems/roberts.rs:47-91                                  (n = 3) */
+    IDAHIP_LORENZ63 = 1,     /* tests/lorenz63.rs:17-25,47-53; params [p, r, b] per system            (n = 3) */
+    IDAHIP_LINEAR_DENSE = 2, /* F = A y' + B y - c, A/B dense column-major per system */
+    IDAHIP_HEAT1D = 3        /* 1-D heat, method of lines; params [kappa/dx^2] per system (config 4)           */
+} idahip_problem;
+
+/* ctx-resident vectors of the reference's IdaNLProblem / Ida structs (src/ida_nls.rs:27-59, src/lib.rs:104-126) */
+typedef enum {
+    IDAHIP_F_YY = 0,
+    IDAHIP_F_YP = 1,
+    IDAHIP_F_YYPREDICT = 2,
+    IDAHIP_F_YPPREDICT = 3,
+    IDAHIP_F_EWT = 4,
+    IDAHIP_F_EE = 5,
+    IDAHIP_F_DELTA = 6, /* Newton::delta (crates/nonlinear/src/newton.rs:21): residual in, update out */
+    IDAHIP_F_SAVRES = 7,
+    IDAHIP_F_PHI0 = 8, /* phi[j] = IDAHIP_F_PHI0 + j, j = 0..5 (MXORDP1 = 6, src/constants.rs:6) */
+    IDAHIP_F_PHI5 = 13
+} idahip_field;
+
+/* ---- lifetime: LS::new(n) + NLS::new(n, maxiters) + IdaNLProblem::new (src/lib.rs:399-400, src/ida_ls.rs:192) ---- */
+int idahip_create(idahip_ctx** ctx, int device, int n, int batch, idahip_problem kind, void* hip_stream /* or NULL */);
+int idahip_destroy(idahip_ctx* ctx);
+const char* idahip_last_error(const idahip_ctx* ctx);
+int idahip_sync(idahip_ctx* ctx);
+int idahip_n(const idahip_ctx* ctx);
+int idahip_batch(const idahip_ctx* ctx);
+
+/* TolControlSS (natol == 1) / TolControlSV (natol == n), src/tol_control.rs:6-82; shared by the ensemble */
+int idahip_set_tolerances(idahip_ctx* ctx, double rtol, const double* hAtol, int natol);
+/* per-system problem parameters, systems [first, first+count): LORENZ63 [count][3], HEAT1D [count][1] */
+int idahip_set_problem_params(idahip_ctx* ctx, int first, int count, const double* hParams, int nparam);
+/* LINEAR_DENSE data, systems [first, first+count): hA, hB [count][n*n] column-major, hC [count][n] */
+int idahip_set_linear_dense(idahip_ctx* ctx, int first, int count, const double* hA, const double* hB, const double* hC);
+/* state movement: field of systems [first, first+count) <-> host [count][n] */
+int idahip_upload(idahip_ctx* ctx, idahip_field f, int first, int count, const double* h);
+int idahip_download(idahip_ctx* ctx, idahip_field f, int first, int count, double* h);
+/* factored Jacobian of one system (column-major n*n), its pivots and the zero-pivot flag -- for tests/inspection */
+int idahip_download_lu(idahip_ctx* ctx, int sys, double* hLU, int64_t* hPiv);
+
+/* raw device memory for the stand-alone solver calls below (so callers need no HIP runtime of their own) */
+void* idahip_dev_alloc(idahip_ctx* ctx, size_t bytes);
+int idahip_dev_free(idahip_ctx* ctx, void* d);
+int idahip_memcpy_h2d(idahip_ctx* ctx, void* d, const void* h, size_t bytes);
+int idahip_memcpy_d2h(idahip_ctx* ctx, void* h, const void* d, size_t bytes);
+
+/* ---- LSolver trait (crates/linear/src/traits.rs:27-91) on caller-owned device buffers [batch][n*n], [batch][n] ----
+ * setup  = Dense::setup  -> dense_get_rf (crates/linear/src/dense.rs:38-44, 86-158): in-place PA = LU, pivots out;
+ *          hInfo[s] = 0 | 1-based zero-pivot column (linear::Error::LUFactFail{col}, crates/linear/src/lib.rs:11-12).
+ * solve  = Dense::solve  -> x <- b; dense_get_rs (dense.rs:46-63, 165-206). `tol` is ignored by a direct solver.   */
+int idahip_ls_setup(idahip_ctx* ctx, double* dA, int64_t* dPiv, int32_t* hInfo, const int32_t* hIdx, int nsys);
+int idahip_ls_solve(idahip_ctx* ctx, const double* dLU, const int64_t* dPiv, double* dX, const double* dB, double tol,
+                    const int32_t* hIdx, int nsys);
+/* NormRms::norm_wrms (src/norm_rms.rs:31-38): hOut[s] = sqrt(sum_i (x_i w_i)^2 / n), summed left to right */
+int idahip_wrms(idahip_ctx* ctx, const double* dX, const double* dW, double* hOut, const int32_t* hIdx, int nsys);
+
+/* ---- NLProblem trait as implemented by IdaNLProblem (src/ida_nls.rs:118-266), on the ctx-resident state ----
+ * sys    = idaNlsResidual (:118-153): yy = yypredict + ycor; yp = yppredict + cj*ycor; delta = savres = F(tn,yy,yp).
+ *          ycor is the accumulated correction `ee` (Newton's y); reset_ee != 0 first sets ee = 0 (Newton's y <- y0 = 0,
+ *          crates/nonlinear/src/newton.rs:75,93).
+ * lsetup = idaNlsLSetup (:156-187) + idaLsSetup (src/ida_ls.rs:232-290): J <- 0; jac(tn, cj, yy, yp, res); LU(J).
+ *          hInfo[s] = 0 | 1-based zero-pivot column (recoverable). The caller resets cjold/cjratio/ss as :177-179.
+ * newton_iter = one pass of the Newton loop body (newton.rs:98-110): delta = -delta; idaNlsLSolve (src/ida_nls.rs:190,
+ *          src/ida_ls.rs:298-455: getrs, then delta *= hScale[s] with hScale = 2/(1+cjratio), or 1.0 when cjratio == 1);
+ *          ee += delta; hDelnrm[s] = ||delta||_wrms(ewt) for idaNlsConvTest (:218-266), which the host evaluates
+ *          (its `powf` must be the platform libm's).                                                   */
+int idahip_nls_sys(idahip_ctx* ctx, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys);
+int idahip_nls_lsetup(idahip_ctx* ctx, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys);
+int idahip_newton_iter(idahip_ctx* ctx, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys);
+
+/* ---- vector parts of the stepper that touch the same device-resident state ----
+ * init_first : initial_setup + first-call block of Ida::solve (src/lib.rs:537-545, src/impl_solve.rs:120-126):
+ *              ewt = ewt_set(phi[0]); hYpnorm[s] = ||phi[1]||_wrms(ewt); hPhi0Nrm[s] = ||phi[0]||_wrms(ewt) (the first
+ *              tolsf test, impl_solve.rs:289-295).
+ * scale_phi1 : phi[1] *= hFac[s]   (phi[1] = hh*y', impl_solve.rs:167-168; reset() after a failed first step)
+ * predict    : set_coeffs' phi-star scaling phi[j] *= beta[j], j = ns..kk (lib.rs:768-779) followed by IDAPredict
+ *              (lib.rs:894-959). hKkNs [nsys][2], hBeta/hGamma [nsys][6].
+ * post_newton: yy = yypredict + ee; yp = yppredict + cj*ee (lib.rs:845-849) and the four norms the error test /
+ *              order selection may need (lib.rs:983-1004, impl_complete_step.rs:74-77):
+ *              hNorms[s] = { ||ee||, ||ee+phi[kk]||, ||ee+phi[kk]+phi[kk-1]||, ||ee-phi[kk+1]|| } (0 where undefined).
+ * restore    : IDARestore's phi part, phi[j] *= cvals[j-ns], j = ns..kk (lib.rs:1057-1082). hCvals [nsys][6].
+ * complete_step: phi[kused+1] = ee (if kused < maxord), the phi recurrence (impl_complete_step.rs:152-176), ee *= ck
+ *              (lib.rs:708), then the next step's ewt_set(phi[0]) and tolsf norm (impl_solve.rs:266-295):
+ *              hPhi0Nrm[s] = ||phi[0]||_wrms(ewt), hEwtBad[s] != 0 if some ewt component <= 0.
+ * get_solution: IDAGetSolution's linear combinations (lib.rs:1319-1340). hCvals [nsys][6], hDvals [nsys][5].       */
+int idahip_init_first(idahip_ctx* ctx, double* hYpnorm, double* hPhi0Nrm, const int32_t* hIdx, int nsys);
+int idahip_scale_phi1(idahip_ctx* ctx, const double* hFac, const int32_t* hIdx, int nsys);
+int idahip_predict(idahip_ctx* ctx, const int32_t* hKkNs, const double* hBeta, const double* hGamma, const int32_t* hIdx, int nsys);
+int idahip_post_newton(idahip_ctx* ctx, const double* hCj, const int32_t* hKk, double* hNorms, const int32_t* hIdx, int nsys);
+int idahip_restore(idahip_ctx* ctx, const int32_t* hKkNs, const double* hCvals, const int32_t* hIdx, int nsys);
+int idahip_complete_step(idahip_ctx* ctx, const int32_t* hKused, const double* hCk, int maxord, double* hPhi0Nrm,
+                         int32_t* hEwtBad, const int32_t* hIdx, int nsys);
+int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCvals, const double* hDvals,
+                        const int32_t* hIdx, int nsys);
+
+/* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the
+ * ctx stream, and launch counters per kernel class ---- */
+typedef enum {
+    IDAHIP_K_NEWTON_ITER = 0, IDAHIP_K_SYS = 1, IDAHIP_K_JAC = 2, IDAHIP_K_LU = 3, IDAHIP_K_VECTOR = 4, IDAHIP_K_SOLVE = 5,
+    IDAHIP_K_COUNT = 6
+} idahip_kclass;
+int idahip_timing_enable(idahip_ctx* ctx, int on);
+/* accumulated device milliseconds and launch count of a kernel class since the last reset */
+int idahip_timing_get(idahip_ctx* ctx, idahip_kclass k, double* ms, int64_t* launches, int64_t* systems);
+int idahip_timing_reset(idahip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDA_HIP_H */

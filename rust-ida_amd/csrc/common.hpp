@@ -1,0 +1,189 @@
+// libidahip -- shared definitions: the ensemble context, per-call argument staging, error plumbing.
+// gfx950 only; fp64; compiled with -ffp-contract=off so device arithmetic is the reference's (no FMA).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ida_hip.h"
+
+namespace idahip {
+
+constexpr int MXORDP1 = 6;      // src/constants.rs:6
+constexpr int TINY_N = 8;       // n <= TINY_N: one thread per system (whole Newton body in registers/L1)
+constexpr int LU_NB = 32;       // panel width of the blocked LU
+constexpr int LU_MAX_N = 1024;  // blocked LU: one panel row per thread, <= 1024 threads
+constexpr int NSLOT = 8;
+
+struct Slot {
+    char* h = nullptr;  // pinned host
+    char* d = nullptr;  // device mirror
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+}  // namespace idahip
+
+struct idahip_ctx {
+    int device = 0;
+    int n = 0;
+    int batch = 0;
+    int npad16 = 0;  // n rounded up to a multiple of 16 (Ubuf row stride)
+    idahip_problem kind = IDAHIP_ROBERTS;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // tolerances
+    double rtol = 0.0;
+    double atol_s = 0.0;
+    double* d_atol_v = nullptr;  // [n] or null
+
+    // state vectors [batch][n]
+    double *yy = nullptr, *yp = nullptr, *yypredict = nullptr, *yppredict = nullptr, *ewt = nullptr, *ee = nullptr,
+           *delta = nullptr, *savres = nullptr;
+    double* phi = nullptr;  // [6][batch][n]
+
+    // linear solver state
+    double* lu = nullptr;    // [batch][n*n] factored Jacobian, reference layout (rows in pivoted order)
+    double* jw = nullptr;    // [batch][n*n] work matrix of the factorisation (physical row order)
+    int64_t* piv = nullptr;  // [batch][n]  reference pivots (dense.rs:118)
+    int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
+    // blocked-LU workspace
+    int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr;
+    double *lu_l11 = nullptr, *lu_ubuf = nullptr;
+
+    // problem data
+    double* params = nullptr;  // [batch][nparam]
+    int nparam = 0;
+    double *A = nullptr, *B = nullptr, *C = nullptr;  // LINEAR_DENSE
+
+    // staging ring
+    idahip::Slot slots[idahip::NSLOT];
+    size_t slot_cap = 0;
+    int next_slot = 0;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double k_ms[IDAHIP_K_COUNT] = {0};
+    int64_t k_launches[IDAHIP_K_COUNT] = {0};
+    int64_t k_systems[IDAHIP_K_COUNT] = {0};
+};
+
+namespace idahip {
+
+inline int fail(idahip_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define IDAHIP_HIP(c, call)                                                                              \
+    do {                                                                                                 \
+        hipError_t e__ = (call);                                                                         \
+        if (e__ != hipSuccess) return idahip::fail((c), -100, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+// One call's host->device arguments and device->host results, carved from a ring slot.
+struct ArgPack {
+    idahip_ctx* c;
+    Slot* s;
+    size_t in_bytes = 0;   // bytes to upload (prefix of the slot)
+    size_t off = 0;
+    size_t out_begin = 0, out_end = 0;
+
+    int begin(idahip_ctx* ctx) {
+        c = ctx;
+        s = &ctx->slots[ctx->next_slot];
+        ctx->next_slot = (ctx->next_slot + 1) % NSLOT;
+        if (s->pending) {
+            IDAHIP_HIP(c, hipEventSynchronize(s->done));
+            s->pending = false;
+        }
+        off = 0;
+        return 0;
+    }
+    static size_t align(size_t x) { return (x + 63) & ~(size_t)63; }
+    // copy `bytes` from host into the slot; returns the device address
+    template <class T>
+    const T* in(const T* src, size_t count) {
+        off = align(off);
+        memcpy(s->h + off, src, count * sizeof(T));
+        const T* d = (const T*)(s->d + off);
+        off += count * sizeof(T);
+        in_bytes = off;
+        return d;
+    }
+    int upload() {
+        if (in_bytes) IDAHIP_HIP(c, hipMemcpyAsync(s->d, s->h, in_bytes, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    // reserve an output region (call after all in()); returns the device address
+    template <class T>
+    T* out(size_t count) {
+        off = align(off);
+        if (out_begin == 0 && out_end == 0) out_begin = off;
+        T* d = (T*)(s->d + off);
+        off += count * sizeof(T);
+        out_end = off;
+        return d;
+    }
+    template <class T>
+    const T* host_of(const T* dptr) const { return (const T*)(s->h + ((const char*)dptr - s->d)); }
+    // download the output region and wait for it
+    int fetch() {
+        if (out_end > out_begin)
+            IDAHIP_HIP(c, hipMemcpyAsync(s->h + out_begin, s->d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, c->stream));
+        IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    // mark the slot busy until the stream reaches this point (calls without results)
+    int finish_async() {
+        IDAHIP_HIP(c, hipEventRecord(s->done, c->stream));
+        s->pending = true;
+        return 0;
+    }
+};
+
+struct KTimer {
+    idahip_ctx* c;
+    idahip_kclass k;
+    KTimer(idahip_ctx* ctx, idahip_kclass kc, int nsys) : c(ctx), k(kc) {
+        c->k_launches[k] += 1;
+        c->k_systems[k] += nsys;
+        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~KTimer() {
+        if (c->timing) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->k_ms[k] += (double)ms;
+        }
+    }
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane /* wave-uniform */) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    const int lo = __shfl_xor(__double2loint(v), mask);
+    const int hi = __shfl_xor(__double2hiint(v), mask);
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace idahip

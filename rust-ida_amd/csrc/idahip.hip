@@ -1,0 +1,653 @@
+// libidahip.so -- implementation of include/ida_hip.h (single translation unit; gfx950; -ffp-contract=off).
+#include "common.hpp"
+#include "lu_kernels.hpp"
+#include "problem_kernels.hpp"
+#include "solve_kernels.hpp"
+#include "vector_kernels.hpp"
+
+using namespace idahip;
+
+namespace {
+
+template <class T>
+int dalloc(idahip_ctx* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return 0;
+    IDAHIP_HIP(c, hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+int check_list(idahip_ctx* c, const int32_t* hIdx, int nsys) {
+    if (!c) return -1;
+    if (nsys < 0 || nsys > c->batch) return fail(c, -2, "nsys = %d out of range (batch = %d)", nsys, c->batch);
+    if (nsys > 0 && !hIdx) return fail(c, -2, "null system list");
+    for (int s = 0; s < nsys; ++s)
+        if (hIdx[s] < 0 || hIdx[s] >= c->batch) return fail(c, -2, "system id %d out of range at list position %d", hIdx[s], s);
+    return 0;
+}
+
+double* field_ptr(idahip_ctx* c, idahip_field f) {
+    switch (f) {
+        case IDAHIP_F_YY: return c->yy;
+        case IDAHIP_F_YP: return c->yp;
+        case IDAHIP_F_YYPREDICT: return c->yypredict;
+        case IDAHIP_F_YPPREDICT: return c->yppredict;
+        case IDAHIP_F_EWT: return c->ewt;
+        case IDAHIP_F_EE: return c->ee;
+        case IDAHIP_F_DELTA: return c->delta;
+        case IDAHIP_F_SAVRES: return c->savres;
+        default: break;
+    }
+    if (f >= IDAHIP_F_PHI0 && f <= IDAHIP_F_PHI5) return c->phi + (size_t)(f - IDAHIP_F_PHI0) * c->batch * c->n;
+    return nullptr;
+}
+
+VecState vec_state(idahip_ctx* c) {
+    VecState s;
+    s.phi = c->phi;
+    s.phistride = (long)c->batch * c->n;
+    s.yy = c->yy; s.yp = c->yp; s.yypredict = c->yypredict; s.yppredict = c->yppredict;
+    s.ewt = c->ewt; s.ee = c->ee; s.delta = c->delta;
+    s.n = c->n;
+    s.rtol = c->rtol; s.atol_s = c->atol_s; s.atol_v = c->d_atol_v;
+    return s;
+}
+
+int post_launch(idahip_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, -101, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem kind, void* hip_stream) {
+    if (!out) return -1;
+    *out = nullptr;
+    if (n < 1 || batch < 1) return -2;
+    if ((kind == IDAHIP_ROBERTS || kind == IDAHIP_LORENZ63) && n != 3) return -2;
+    idahip_ctx* c = new idahip_ctx();
+    c->device = device; c->n = n; c->batch = batch; c->kind = kind;
+    c->npad16 = (n + 15) & ~15;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete c; return -100; }
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -100; }
+        c->own_stream = true;
+    }
+    const size_t bn = (size_t)batch * n, bnn = bn * n;
+    int rc = 0;
+    rc |= dalloc(c, &c->yy, bn); rc |= dalloc(c, &c->yp, bn); rc |= dalloc(c, &c->yypredict, bn); rc |= dalloc(c, &c->yppredict, bn);
+    rc |= dalloc(c, &c->ewt, bn); rc |= dalloc(c, &c->ee, bn); rc |= dalloc(c, &c->delta, bn); rc |= dalloc(c, &c->savres, bn);
+    rc |= dalloc(c, &c->phi, (size_t)MXORDP1 * bn);
+    rc |= dalloc(c, &c->lu, bnn); rc |= dalloc(c, &c->piv, bn); rc |= dalloc(c, &c->perm, bn);
+    rc |= dalloc(c, &c->lu_info, (size_t)batch);
+    if (n > TINY_N) {
+        rc |= dalloc(c, &c->jw, bnn);
+        rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
+        rc |= dalloc(c, &c->lu_uz, (size_t)batch * (c->npad16 / 16));
+        rc |= dalloc(c, &c->lu_l11, (size_t)batch * LU_NB * LU_NB);
+        rc |= dalloc(c, &c->lu_ubuf, (size_t)batch * LU_NB * c->npad16);
+    }
+    if (kind == IDAHIP_LINEAR_DENSE) {
+        rc |= dalloc(c, &c->A, bnn); rc |= dalloc(c, &c->B, bnn); rc |= dalloc(c, &c->C, bn);
+    }
+    if (kind == IDAHIP_LORENZ63) { c->nparam = 3; rc |= dalloc(c, &c->params, (size_t)batch * 3); }
+    if (kind == IDAHIP_HEAT1D) { c->nparam = 1; rc |= dalloc(c, &c->params, (size_t)batch); }
+    c->slot_cap = (size_t)batch * 192 + 4096;
+    for (int i = 0; i < NSLOT && !rc; ++i) {
+        if (hipHostMalloc((void**)&c->slots[i].h, c->slot_cap) != hipSuccess) rc = -100;
+        else if (hipMalloc((void**)&c->slots[i].d, c->slot_cap) != hipSuccess) rc = -100;
+        else if (hipEventCreateWithFlags(&c->slots[i].done, hipEventDisableTiming) != hipSuccess) rc = -100;
+    }
+    if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) rc = -100;
+    if (rc) {
+        idahip_destroy(c);
+        return -100;
+    }
+    // deterministic initial contents
+    (void)hipMemsetAsync(c->ee, 0, bn * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->delta, 0, bn * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->phi, 0, (size_t)MXORDP1 * bn * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->lu_info, 0, (size_t)batch * sizeof(int), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    *out = c;
+    return 0;
+}
+
+int idahip_destroy(idahip_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->lu_ubuf, c->params, c->A, c->B, c->C, c->d_atol_v};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < NSLOT; ++i) {
+        if (c->slots[i].h) (void)hipHostFree(c->slots[i].h);
+        if (c->slots[i].d) (void)hipFree(c->slots[i].d);
+        if (c->slots[i].done) (void)hipEventDestroy(c->slots[i].done);
+    }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+const char* idahip_last_error(const idahip_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+int idahip_n(const idahip_ctx* c) { return c ? c->n : -1; }
+int idahip_batch(const idahip_ctx* c) { return c ? c->batch : -1; }
+
+int idahip_sync(idahip_ctx* c) {
+    if (!c) return -1;
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int idahip_set_tolerances(idahip_ctx* c, double rtol, const double* hAtol, int natol) {
+    if (!c || !hAtol) return -1;
+    if (natol != 1 && natol != c->n) return fail(c, -2, "natol must be 1 or n");
+    c->rtol = rtol;
+    if (natol == 1 && c->n != 1) {
+        c->atol_s = hAtol[0];
+        if (c->d_atol_v) { (void)hipFree(c->d_atol_v); c->d_atol_v = nullptr; }
+    } else {
+        c->atol_s = hAtol[0];
+        if (!c->d_atol_v) { int rc = dalloc(c, &c->d_atol_v, (size_t)c->n); if (rc) return rc; }
+        IDAHIP_HIP(c, hipMemcpy(c->d_atol_v, hAtol, sizeof(double) * c->n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int idahip_set_problem_params(idahip_ctx* c, int first, int count, const double* hParams, int nparam) {
+    if (!c || !hParams) return -1;
+    if (!c->params || nparam != c->nparam) return fail(c, -2, "problem kind takes %d parameters per system", c->nparam);
+    if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
+    IDAHIP_HIP(c, hipMemcpy(c->params + (size_t)first * nparam, hParams, sizeof(double) * count * nparam, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int idahip_set_linear_dense(idahip_ctx* c, int first, int count, const double* hA, const double* hB, const double* hC) {
+    if (!c || !hA || !hB || !hC) return -1;
+    if (c->kind != IDAHIP_LINEAR_DENSE) return fail(c, -2, "not a LINEAR_DENSE ctx");
+    if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
+    const size_t nn = (size_t)c->n * c->n;
+    IDAHIP_HIP(c, hipMemcpy(c->A + first * nn, hA, sizeof(double) * count * nn, hipMemcpyHostToDevice));
+    IDAHIP_HIP(c, hipMemcpy(c->B + first * nn, hB, sizeof(double) * count * nn, hipMemcpyHostToDevice));
+    IDAHIP_HIP(c, hipMemcpy(c->C + (size_t)first * c->n, hC, sizeof(double) * count * c->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int idahip_upload(idahip_ctx* c, idahip_field f, int first, int count, const double* h) {
+    if (!c || !h) return -1;
+    double* d = field_ptr(c, f);
+    if (!d) return fail(c, -2, "unknown field %d", (int)f);
+    if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipMemcpy(d + (size_t)first * c->n, h, sizeof(double) * count * c->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int idahip_download(idahip_ctx* c, idahip_field f, int first, int count, double* h) {
+    if (!c || !h) return -1;
+    double* d = field_ptr(c, f);
+    if (!d) return fail(c, -2, "unknown field %d", (int)f);
+    if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipMemcpy(h, d + (size_t)first * c->n, sizeof(double) * count * c->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int idahip_download_lu(idahip_ctx* c, int sys, double* hLU, int64_t* hPiv) {
+    if (!c) return -1;
+    if (sys < 0 || sys >= c->batch) return fail(c, -2, "system out of range");
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t nn = (size_t)c->n * c->n;
+    if (hLU) IDAHIP_HIP(c, hipMemcpy(hLU, c->lu + sys * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    if (hPiv) IDAHIP_HIP(c, hipMemcpy(hPiv, c->piv + (size_t)sys * c->n, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void* idahip_dev_alloc(idahip_ctx* c, size_t bytes) {
+    void* p = nullptr;
+    if (!c || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+int idahip_dev_free(idahip_ctx* c, void* d) {
+    if (!c) return -1;
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipFree(d));
+    return 0;
+}
+int idahip_memcpy_h2d(idahip_ctx* c, void* d, const void* h, size_t bytes) {
+    if (!c) return -1;
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int idahip_memcpy_d2h(idahip_ctx* c, void* h, const void* d, size_t bytes) {
+    if (!c) return -1;
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LSolver
+int idahip_ls_setup(idahip_ctx* c, double* dA, int64_t* dPiv, int32_t* hInfo, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!dA || !dPiv || !hInfo) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    const long nn = (long)n * n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_LU, nsys);
+        if (n <= TINY_N) {
+            rc = lu_factor_batched(c, dA, nn, dA, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
+        } else {
+            // factor in place in dA (physical row order), scatter rows into the ctx work matrix, copy back
+            rc = lu_factor_batched(c, dA, nn, c->jw, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
+            if (!rc) {
+                for (int s = 0; s < nsys; ++s)  // listed systems only; info != 0 systems keep their partial factors
+                    (void)hipMemcpyAsync(dA + hIdx[s] * nn, c->jw + hIdx[s] * nn, sizeof(double) * nn, hipMemcpyDeviceToDevice, c->stream);
+            }
+        }
+        if (rc) return rc;
+        if ((rc = post_launch(c, "lu"))) return rc;
+    }
+    std::vector<int32_t> info(c->batch);
+    IDAHIP_HIP(c, hipMemcpyAsync(info.data(), c->lu_info, sizeof(int32_t) * c->batch, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    int any = 0;
+    for (int s = 0; s < nsys; ++s) {
+        hInfo[s] = info[hIdx[s]];
+        any |= hInfo[s] != 0;
+    }
+    return any ? 1 : 0;
+}
+
+int idahip_ls_solve(idahip_ctx* c, const double* dLU, const int64_t* dPiv, double* dX, const double* dB, double /*tol*/,
+                    const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!dLU || !dPiv || !dX || !dB) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_SOLVE, nsys);
+        if (n <= TINY_N) {
+            hipLaunchKernelGGL(tiny_solve_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, dLU, (long)n * n, (const long long*)dPiv,
+                               (long)n, dX, dB, n, d_idx, nsys);
+        } else {
+            const size_t shm = sizeof(double) * n + sizeof(int) * n;
+            if (n % 2 == 0)
+                hipLaunchKernelGGL(ls_solve_kernel<2>, dim3(nsys), dim3(256), shm, c->stream, dLU, (long)n * n, (const long long*)dPiv,
+                                   (long)n, (const int*)nullptr, dX, dB, n, d_idx);
+            else
+                hipLaunchKernelGGL(ls_solve_kernel<1>, dim3(nsys), dim3(256), shm, c->stream, dLU, (long)n * n, (const long long*)dPiv,
+                                   (long)n, (const int*)nullptr, dX, dB, n, d_idx);
+        }
+        if ((rc = post_launch(c, "ls_solve"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_wrms(idahip_ctx* c, const double* dX, const double* dW, double* hOut, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!dX || !dW || !hOut) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    double* d_out = ap.out<double>(nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        if (n <= TINY_N)
+            hipLaunchKernelGGL(tiny_wrms_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, dX, dW, d_out, n, d_idx, nsys);
+        else
+            hipLaunchKernelGGL(wrms_kernel, dim3(nsys), dim3(256), sizeof(double) * n, c->stream, dX, dW, d_out, n, d_idx);
+        if ((rc = post_launch(c, "wrms"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* h = ap.host_of(d_out);
+    for (int s = 0; s < nsys; ++s) hOut[s] = sqrt(h[s] / (double)n);  // divide, then sqrt: host libm (norm_rms.rs:36-37)
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ NLProblem
+int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hTn || !hCj) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    SysArgs a;
+    a.idx = ap.in(hIdx, nsys);
+    a.tn = ap.in(hTn, nsys);
+    a.cj = ap.in(hCj, nsys);
+    if ((rc = ap.upload())) return rc;
+    a.yypredict = c->yypredict; a.yppredict = c->yppredict; a.yy = c->yy; a.yp = c->yp; a.ee = c->ee; a.delta = c->delta;
+    a.savres = c->savres; a.n = n; a.reset_ee = reset_ee;
+    {
+        KTimer kt(c, IDAHIP_K_SYS, nsys);
+        switch (c->kind) {
+            case IDAHIP_ROBERTS:
+                hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)nullptr, 0, nsys);
+                break;
+            case IDAHIP_LORENZ63:
+                hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)c->params, 3, nsys);
+                break;
+            case IDAHIP_LINEAR_DENSE:
+                if (n % 2 == 0)
+                    hipLaunchKernelGGL(linear_sys_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, a, (const double*)c->A,
+                                       (const double*)c->B, (const double*)c->C);
+                else
+                    hipLaunchKernelGGL(linear_sys_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, a, (const double*)c->A,
+                                       (const double*)c->B, (const double*)c->C);
+                break;
+            case IDAHIP_HEAT1D:
+                hipLaunchKernelGGL(heat_sys_kernel, dim3(nsys), dim3(256), sizeof(double) * n, c->stream, a, (const double*)c->params);
+                break;
+        }
+        if ((rc = post_launch(c, "nls_sys"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    const long nn = (long)n * n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const double* d_cj = ap.in(hCj, nsys);
+    if ((rc = ap.upload())) return rc;
+    double* work = (n <= TINY_N) ? c->lu : c->jw;
+    {
+        KTimer kt(c, IDAHIP_K_JAC, nsys);
+        switch (c->kind) {
+            case IDAHIP_ROBERTS:
+                hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
+                                   (const double*)nullptr, 0, d_idx, d_cj, nsys);
+                break;
+            case IDAHIP_LORENZ63:
+                hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
+                                   (const double*)c->params, 3, d_idx, d_cj, nsys);
+                break;
+            case IDAHIP_LINEAR_DENSE: {
+                int chunks = 1;
+                while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
+                hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A, (const double*)c->B, nn,
+                                   d_idx, d_cj, chunks);
+                break;
+            }
+            case IDAHIP_HEAT1D: {
+                int chunks = 1;
+                while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
+                hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+                break;
+            }
+        }
+        if ((rc = post_launch(c, "jac"))) return rc;
+    }
+    {
+        KTimer kt(c, IDAHIP_K_LU, nsys);
+        rc = lu_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys);
+        if (rc) return rc;
+        if ((rc = post_launch(c, "lu"))) return rc;
+    }
+    std::vector<int32_t> info(c->batch);
+    IDAHIP_HIP(c, hipMemcpyAsync(info.data(), c->lu_info, sizeof(int32_t) * c->batch, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    int any = 0;
+    for (int s = 0; s < nsys; ++s) {
+        hInfo[s] = info[hIdx[s]];
+        any |= hInfo[s] != 0;
+    }
+    return any ? 1 : 0;
+}
+
+int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hScale || !hDelnrm) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const double* d_scale = ap.in(hScale, nsys);
+    double* d_out = ap.out<double>(nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_NEWTON_ITER, nsys);
+        if (n <= TINY_N) {
+            hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
+                               (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out);
+        } else if (n % 2 == 0) {
+            hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out);
+        } else {
+            hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out);
+        }
+        if ((rc = post_launch(c, "newton_iter"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* h = ap.host_of(d_out);
+    for (int s = 0; s < nsys; ++s) hDelnrm[s] = sqrt(h[s] / (double)n);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stepper vector ops
+int idahip_init_first(idahip_ctx* c, double* hYpnorm, double* hPhi0Nrm, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hYpnorm || !hPhi0Nrm) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    double* d_out = ap.out<double>(2 * (size_t)nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(init_first_kernel, dim3(nsys), dim3(256), 2 * sizeof(double) * c->n, c->stream, vec_state(c), d_idx, d_out);
+        if ((rc = post_launch(c, "init_first"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* h = ap.host_of(d_out);
+    for (int s = 0; s < nsys; ++s) {
+        hYpnorm[s] = sqrt(h[2 * s] / (double)c->n);
+        hPhi0Nrm[s] = sqrt(h[2 * s + 1] / (double)c->n);
+    }
+    return 0;
+}
+
+int idahip_scale_phi1(idahip_ctx* c, const double* hFac, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hFac) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const double* d_fac = ap.in(hFac, nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(scale_phi1_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_fac);
+        if ((rc = post_launch(c, "scale_phi1"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_predict(idahip_ctx* c, const int32_t* hKkNs, const double* hBeta, const double* hGamma, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hKkNs || !hBeta || !hGamma) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKkNs[2 * s] < 1 || hKkNs[2 * s] >= MXORDP1 || hKkNs[2 * s + 1] < 0) return fail(c, -2, "bad kk/ns at list position %d", s);
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const int* d_kkns = ap.in(hKkNs, 2 * (size_t)nsys);
+    const double* d_beta = ap.in(hBeta, (size_t)MXORDP1 * nsys);
+    const double* d_gamma = ap.in(hGamma, (size_t)MXORDP1 * nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(predict_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_kkns, d_beta, d_gamma);
+        if ((rc = post_launch(c, "predict"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_post_newton(idahip_ctx* c, const double* hCj, const int32_t* hKk, double* hNorms, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hCj || !hKk || !hNorms) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKk[s] < 1 || hKk[s] >= MXORDP1) return fail(c, -2, "bad kk at list position %d", s);
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const double* d_cj = ap.in(hCj, nsys);
+    const int* d_kk = ap.in(hKk, nsys);
+    double* d_out = ap.out<double>(4 * (size_t)nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(post_newton_kernel, dim3(nsys), dim3(256), 4 * sizeof(double) * c->n, c->stream, vec_state(c), d_idx, d_cj, d_kk, d_out);
+        if ((rc = post_launch(c, "post_newton"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* h = ap.host_of(d_out);
+    for (size_t e = 0; e < 4 * (size_t)nsys; ++e) hNorms[e] = sqrt(h[e] / (double)c->n);
+    return 0;
+}
+
+int idahip_restore(idahip_ctx* c, const int32_t* hKkNs, const double* hCvals, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hKkNs || !hCvals) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKkNs[2 * s] < 1 || hKkNs[2 * s] >= MXORDP1 || hKkNs[2 * s + 1] < 0) return fail(c, -2, "bad kk/ns at list position %d", s);
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const int* d_kkns = ap.in(hKkNs, 2 * (size_t)nsys);
+    const double* d_cv = ap.in(hCvals, (size_t)MXORDP1 * nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(restore_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_kkns, d_cv);
+        if ((rc = post_launch(c, "restore"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_complete_step(idahip_ctx* c, const int32_t* hKused, const double* hCk, int maxord, double* hPhi0Nrm, int32_t* hEwtBad,
+                         const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hKused || !hCk || !hPhi0Nrm || !hEwtBad) return fail(c, -2, "null argument");
+    if (maxord < 1 || maxord > 5) return fail(c, -2, "bad maxord");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKused[s] < 1 || hKused[s] > maxord) return fail(c, -2, "bad kused at list position %d", s);
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const int* d_ku = ap.in(hKused, nsys);
+    const double* d_ck = ap.in(hCk, nsys);
+    double* d_out = ap.out<double>(nsys);
+    int* d_bad = ap.out<int>(nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(complete_step_kernel, dim3(nsys), dim3(256), sizeof(double) * c->n, c->stream, vec_state(c), d_idx, d_ku, d_ck, maxord,
+                           d_out, d_bad);
+        if ((rc = post_launch(c, "complete_step"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* h = ap.host_of(d_out);
+    const int* hb = ap.host_of(d_bad);
+    for (int s = 0; s < nsys; ++s) {
+        hPhi0Nrm[s] = sqrt(h[s] / (double)c->n);
+        hEwtBad[s] = hb[s];
+    }
+    return 0;
+}
+
+int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCvals, const double* hDvals, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hKord || !hCvals || !hDvals) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKord[s] < 1 || hKord[s] > 5) return fail(c, -2, "bad kord at list position %d", s);
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const int* d_ko = ap.in(hKord, nsys);
+    const double* d_cv = ap.in(hCvals, (size_t)MXORDP1 * nsys);
+    const double* d_dv = ap.in(hDvals, (size_t)5 * nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(get_solution_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_ko, d_cv, d_dv);
+        if ((rc = post_launch(c, "get_solution"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+int idahip_timing_enable(idahip_ctx* c, int on) {
+    if (!c) return -1;
+    c->timing = on != 0;
+    return 0;
+}
+int idahip_timing_get(idahip_ctx* c, idahip_kclass k, double* ms, int64_t* launches, int64_t* systems) {
+    if (!c || k < 0 || k >= IDAHIP_K_COUNT) return -1;
+    if (ms) *ms = c->k_ms[k];
+    if (launches) *launches = c->k_launches[k];
+    if (systems) *systems = c->k_systems[k];
+    return 0;
+}
+int idahip_timing_reset(idahip_ctx* c) {
+    if (!c) return -1;
+    for (int k = 0; k < IDAHIP_K_COUNT; ++k) {
+        c->k_ms[k] = 0.0;
+        c->k_launches[k] = 0;
+        c->k_systems[k] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// Device residual / Jacobian kernels: the `Residual::res` / `Jacobian::jac` user callbacks of
+// /root/reference/src/traits.rs:12-70, fused with idaNlsResidual (/root/reference/src/ida_nls.rs:118-153):
+//     yy = yypredict + ycor;  yp = yppredict + cj*ycor (mul, then add);  delta = savres = F(tn, yy, yp).
+// ycor is the accumulated Newton correction `ee` (zeroed first when reset_ee is set).
+//
+//   Roberts      <- /root/reference/src/sample_problems/roberts.rs:47-91 (operation order kept verbatim)
+//   Lorenz63     <- /root/reference/tests/lorenz63.rs:17-25,47-53 (parameters + commented RHS; expression order ours)
+//   LinearDense  <- SURVEY.md 8(d) config 3: F = A y' + B y - c with the summation order fixed in
+//                   oracle/problems.hpp (two left-to-right chains over ascending column j) -- which is exactly
+//                   what a thread-per-row, column-sweeping GPU kernel computes, with coalesced 16-byte loads.
+//   Heat1D       <- SURVEY.md 8(d) config 4.
+#pragma once
+#include "common.hpp"
+
+namespace idahip {
+
+struct SysArgs {
+    const double* yypredict;
+    const double* yppredict;
+    double* yy;
+    double* yp;
+    double* ee;
+    double* delta;
+    double* savres;
+    const int* idx;
+    const double* tn;  // [nsys]
+    const double* cj;  // [nsys]
+    int n;
+    int reset_ee;
+};
+
+// ------------------------------------------------------------------------------------------------ tiny problems
+__device__ __forceinline__ void roberts_res(const double* yy, const double* yp, double* r) {
+    r[0] = -0.04 * yy[0] + 1.0e4 * yy[1] * yy[2];
+    r[1] = -r[0] - 3.0e7 * yy[1] * yy[1] - yp[1];
+    r[0] -= yp[0];
+    r[2] = yy[0] + yy[1] + yy[2] - 1.0;
+}
+__device__ __forceinline__ void roberts_jac(double cj, const double* yy, double* J) {
+    J[0] = -0.04 - cj;               J[3] = 1.0e4 * yy[2];                          J[6] = 1.0e4 * yy[1];
+    J[1] = 0.04;                     J[4] = -1.0e4 * yy[2] - 6.0e7 * yy[1] - cj;    J[7] = -1.0e4 * yy[1];
+    J[2] = 1.0;                      J[5] = 1.0;                                    J[8] = 1.0;
+}
+__device__ __forceinline__ void lorenz_res(const double* prm, const double* y, const double* yp, double* f) {
+    const double p = prm[0], r = prm[1], b = prm[2];
+    f[0] = yp[0] - p * (y[1] - y[0]);
+    f[1] = yp[1] - (y[0] * (r - y[2]) - y[1]);
+    f[2] = yp[2] - (y[0] * y[1] - b * y[2]);
+}
+__device__ __forceinline__ void lorenz_jac(const double* prm, double cj, const double* y, double* J) {
+    const double p = prm[0], r = prm[1], b = prm[2];
+    J[0] = p + cj;        J[3] = -p;         J[6] = 0.0;
+    J[1] = -(r - y[2]);   J[4] = 1.0 + cj;   J[7] = y[0];
+    J[2] = -y[1];         J[5] = -y[0];      J[8] = b + cj;
+}
+
+template <int KIND>
+__global__ void tiny_sys_kernel(SysArgs a, const double* __restrict__ params, int nparam, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = a.idx[s];
+    const long vb = (long)b * 3;
+    const double cj = a.cj[s];
+    double yy[3], yp[3], r[3];
+    for (int i = 0; i < 3; ++i) {
+        double yc = a.ee[vb + i];
+        if (a.reset_ee) {
+            yc = 0.0;
+            a.ee[vb + i] = 0.0;
+        }
+        yy[i] = a.yypredict[vb + i] + yc;
+        yp[i] = a.yppredict[vb + i] + cj * yc;
+        a.yy[vb + i] = yy[i];
+        a.yp[vb + i] = yp[i];
+    }
+    if (KIND == IDAHIP_ROBERTS) roberts_res(yy, yp, r);
+    else lorenz_res(params + (long)b * nparam, yy, yp, r);
+    for (int i = 0; i < 3; ++i) {
+        a.delta[vb + i] = r[i];
+        a.savres[vb + i] = r[i];
+    }
+}
+
+// J <- 0; jac(tn, cj, yy, yp, res) -- into mats[b] (column-major)
+template <int KIND>
+__global__ void tiny_jac_kernel(double* mats, const double* __restrict__ yy, const double* __restrict__ params, int nparam,
+                                const int* idx, const double* cjs, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = idx[s];
+    double y[3], J[9];
+    for (int i = 0; i < 3; ++i) y[i] = yy[(long)b * 3 + i];
+    if (KIND == IDAHIP_ROBERTS) roberts_jac(cjs[s], y, J);
+    else lorenz_jac(params + (long)b * nparam, cjs[s], y, J);
+    for (int e = 0; e < 9; ++e) mats[(long)b * 9 + e] = J[e];
+}
+
+// ------------------------------------------------------------------------------------------------ linear dense
+// One workgroup (256 threads) per system; thread t owns rows {VEC*t + v + VEC*256*pass}; sweeps columns j ascending.
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double* __restrict__ A, const double* __restrict__ Bm,
+                                                         const double* __restrict__ C) {
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n;
+    double* syy = sm;
+    double* syp = sm + n;
+    const int b = a.idx[blockIdx.x];
+    const long vb = (long)b * n;
+    const double cj = a.cj[blockIdx.x];
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += 256) {
+        double yc = a.ee[vb + i];
+        if (a.reset_ee) {
+            yc = 0.0;
+            a.ee[vb + i] = 0.0;
+        }
+        const double y = a.yypredict[vb + i] + yc;
+        const double yp = a.yppredict[vb + i] + cj * yc;
+        a.yy[vb + i] = y;
+        a.yp[vb + i] = yp;
+        syy[i] = y;
+        syp[i] = yp;
+    }
+    __syncthreads();
+    const double* __restrict__ Ab = A + (long)b * n * n;
+    const double* __restrict__ Bb = Bm + (long)b * n * n;
+    for (int i = VEC * t; i < n; i += VEC * 256) {
+        double ra[VEC], rb[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ra[v] = rb[v] = 0.0;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            double av[8][VEC], bv[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double* pa = Ab + (long)(j + u) * n + i;
+                const double* pb = Bb + (long)(j + u) * n + i;
+                if constexpr (VEC == 2) {
+                    const double2 qa = *reinterpret_cast<const double2*>(pa);
+                    const double2 qb = *reinterpret_cast<const double2*>(pb);
+                    av[u][0] = qa.x; av[u][1] = qa.y;
+                    bv[u][0] = qb.x; bv[u][1] = qb.y;
+                } else {
+                    av[u][0] = *pa;
+                    bv[u][0] = *pb;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double ypj = syp[j + u], yyj = syy[j + u];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    ra[v] = ra[v] + av[u][v] * ypj;
+                    rb[v] = rb[v] + bv[u][v] * yyj;
+                }
+            }
+        }
+        for (; j < n; ++j) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (i + v < n) {
+                    ra[v] = ra[v] + Ab[(long)j * n + i + v] * syp[j];
+                    rb[v] = rb[v] + Bb[(long)j * n + i + v] * syy[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (i + v < n) {
+                const double r = (ra[v] + rb[v]) - C[vb + i + v];
+                a.delta[vb + i + v] = r;
+                a.savres[vb + i + v] = r;
+            }
+        }
+    }
+}
+
+// J = B + cj*A (mul, then add), elementwise over the listed systems
+__global__ __launch_bounds__(256) void linear_jac_kernel(double* __restrict__ mats, const double* __restrict__ A, const double* __restrict__ Bm,
+                                                         long nn, const int* __restrict__ idx, const double* __restrict__ cjs, int chunks) {
+    const int b = idx[blockIdx.x];
+    const double cj = cjs[blockIdx.x];
+    const long per = (nn + chunks - 1) / chunks;
+    const long beg = (long)blockIdx.y * per;
+    const long end = (beg + per < nn) ? beg + per : nn;
+    const double* __restrict__ Ab = A + (long)b * nn;
+    const double* __restrict__ Bb = Bm + (long)b * nn;
+    double* __restrict__ J = mats + (long)b * nn;
+    if ((nn & 1) == 0 && (beg & 1) == 0) {
+        for (long e = beg + 2 * threadIdx.x; e < end; e += 512) {
+            if (e + 1 < end) {
+                const double2 qa = *reinterpret_cast<const double2*>(Ab + e);
+                const double2 qb = *reinterpret_cast<const double2*>(Bb + e);
+                double2 o;
+                o.x = qb.x + cj * qa.x;
+                o.y = qb.y + cj * qa.y;
+                *reinterpret_cast<double2*>(J + e) = o;
+            } else {
+                J[e] = Bb[e] + cj * Ab[e];
+            }
+        }
+    } else {
+        for (long e = beg + threadIdx.x; e < end; e += 256) J[e] = Bb[e] + cj * Ab[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ heat 1-D
+__global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* __restrict__ params) {
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n;
+    double* syy = sm;
+    const int b = a.idx[blockIdx.x];
+    const long vb = (long)b * n;
+    const double cj = a.cj[blockIdx.x];
+    const double coef = params[b];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double yc = a.ee[vb + i];
+        if (a.reset_ee) {
+            yc = 0.0;
+            a.ee[vb + i] = 0.0;
+        }
+        const double y = a.yypredict[vb + i] + yc;
+        const double yp = a.yppredict[vb + i] + cj * yc;
+        a.yy[vb + i] = y;
+        a.yp[vb + i] = yp;
+        syy[i] = y;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double r;
+        if (i == 0 || i == n - 1) r = syy[i];
+        else r = a.yp[vb + i] - coef * ((syy[i - 1] - 2.0 * syy[i]) + syy[i + 1]);
+        a.delta[vb + i] = r;
+        a.savres[vb + i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats, int n, const double* __restrict__ params,
+                                                       const int* __restrict__ idx, const double* __restrict__ cjs, int chunks) {
+    const int b = idx[blockIdx.x];
+    const double cj = cjs[blockIdx.x];
+    const double coef = params[b];
+    double* __restrict__ J = mats + (long)b * n * n;
+    const int per = (n + chunks - 1) / chunks;  // columns per block
+    const int jbeg = blockIdx.y * per;
+    const int jend = (jbeg + per < n) ? jbeg + per : n;
+    for (int j = jbeg; j < jend; ++j) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            double v = 0.0;
+            if (i == 0 || i == n - 1) {
+                v = (j == i) ? 1.0 : 0.0;
+            } else {
+                if (j == i) v = cj + 2.0 * coef;
+                else if (j == i - 1 || j == i + 1) v = -coef;
+            }
+            J[(long)j * n + i] = v;
+        }
+    }
+}
+
+}  // namespace idahip

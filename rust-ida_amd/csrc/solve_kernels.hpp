@@ -1,0 +1,319 @@
+// Batched triangular solves, the fused Newton-iteration body and the WRMS norm for gfx950.
+//   dense_get_rs           <- /root/reference/crates/linear/src/dense.rs:165-206
+//   Newton loop body       <- /root/reference/crates/nonlinear/src/newton.rs:98-110
+//   idaNlsLSolve/idaLsSolve<- /root/reference/src/ida_nls.rs:190-215, /root/reference/src/ida_ls.rs:298-455
+//   norm_wrms              <- /root/reference/src/norm_rms.rs:31-38
+//
+// Bit-exactness: each b_i receives b_i -= a_ik * b_k in ascending (forward) / descending (backward) k exactly as
+// the reference's column-oriented loops do; unfused mul/sub; true division by u_kk. The WRMS sum is accumulated
+// left to right by one lane (512 dependent adds ~ 2 us, hidden behind the other resident workgroups' streaming);
+// the final sqrt(sum/N) is done by the host libm so the norm equals the reference's to the last bit.
+//
+// Performance model: the solve reads every LU entry once (8 N^2 B) in coalesced column segments, 16 B per lane;
+// it is HBM-bound, so the kernel keeps registers low (8 workgroups of 256 threads per CU) and lets workgroups of
+// different systems overlap the short serial diagonal phases with each other's streaming.
+#pragma once
+#include "common.hpp"
+
+namespace idahip {
+
+// Sequential sum of sq[0..n) by the calling lane (LDS source), left to right from 0.0.
+__device__ __forceinline__ double seq_sum_lds(const double* sq, int n) {
+    double s = 0.0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const double a0 = sq[i], a1 = sq[i + 1], a2 = sq[i + 2], a3 = sq[i + 3], a4 = sq[i + 4], a5 = sq[i + 5], a6 = sq[i + 6],
+                     a7 = sq[i + 7];
+        s = s + a0; s = s + a1; s = s + a2; s = s + a3; s = s + a4; s = s + a5; s = s + a6; s = s + a7;
+    }
+    for (; i < n; ++i) s = s + sq[i];
+    return s;
+}
+
+// Workgroup-cooperative getrs on the right-hand side held in LDS (bs[0..n)). blockDim.x == 256.
+// VEC = 2 requires n even (16-byte aligned column segments).
+template <int VEC>
+__device__ void wg_getrs(const double* __restrict__ LU, int n, double* bs) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int T = 256;
+    constexpr int UNR = 8;
+
+    // ---- forward: L y = b, unit diagonal (dense.rs:188-194)
+#pragma unroll 1
+    for (int kb = 0; kb < n; kb += 64) {
+        const int kw = (n - kb) < 64 ? (n - kb) : 64;
+        if (wave == 0) {
+            const int i = kb + lane;
+            double bi = (lane < kw) ? bs[i] : 0.0;
+#pragma unroll 1
+            for (int k0 = 0; k0 + 1 < kw; k0 += UNR) {
+                double lik[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = k0 + u;
+                    lik[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = k0 + u;
+                    if (k + 1 < kw) {
+                        const double bk = readlane_f64(bi, k);
+                        if (lane > k && lane < kw) bi -= lik[u] * bk;
+                    }
+                }
+            }
+            if (lane < kw) bs[i] = bi;
+        }
+        __syncthreads();
+        const int ibeg = kb + 64;
+        if (ibeg < n) {  // rows below a full 64-column block
+#pragma unroll 1
+            for (int i = ibeg + VEC * t; i < n; i += VEC * T) {
+                double acc[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = (i + v < n) ? bs[i + v] : 0.0;
+#pragma unroll 1
+                for (int k = 0; k < 64; k += UNR) {
+                    double lv[UNR][VEC];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const double* p = LU + (long)(kb + k + u) * n + i;
+                        if constexpr (VEC == 2) {
+                            const double2 q = *reinterpret_cast<const double2*>(p);
+                            lv[u][0] = q.x;
+                            lv[u][1] = q.y;
+                        } else {
+                            lv[u][0] = *p;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const double bk = bs[kb + k + u];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] -= lv[u][v] * bk;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (i + v < n) bs[i + v] = acc[v];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- backward: U x = y (dense.rs:197-205): b_k /= u_kk, then b_i -= u_ik b_k for i < k, k descending
+    const int nblk = (n + 63) / 64;
+#pragma unroll 1
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int kb = blk * 64;
+        const int kw = (n - kb) < 64 ? (n - kb) : 64;
+        if (wave == 0) {
+            const int i = kb + lane;
+            double bi = (lane < kw) ? bs[i] : 0.0;
+#pragma unroll 1
+            for (int k0 = kw - 1; k0 >= 0; k0 -= UNR) {
+                double uik[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = k0 - u;
+                    uik[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = k0 - u;
+                    if (k >= 0) {
+                        if (lane == k) bi = bi / uik[u];
+                        const double bk = readlane_f64(bi, k);
+                        if (lane < k) bi -= uik[u] * bk;
+                    }
+                }
+            }
+            if (lane < kw) bs[i] = bi;
+        }
+        __syncthreads();
+        if (kb > 0) {
+#pragma unroll 1
+            for (int i = VEC * t; i < kb; i += VEC * T) {  // kb is a multiple of 64 (hence even): i + v < kb
+                double acc[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = bs[i + v];
+#pragma unroll 1
+                for (int k0 = kw - 1; k0 >= 0; k0 -= UNR) {
+                    double uv[UNR][VEC];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int k = (k0 - u) >= 0 ? (k0 - u) : 0;
+                        const double* p = LU + (long)(kb + k) * n + i;
+                        if constexpr (VEC == 2) {
+                            const double2 q = *reinterpret_cast<const double2*>(p);
+                            uv[u][0] = q.x;
+                            uv[u][1] = q.y;
+                        } else {
+                            uv[u][0] = *p;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int k = k0 - u;
+                        if (k >= 0) {
+                            const double bk = bs[kb + k];
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[v] -= uv[u][v] * bk;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) bs[i + v] = acc[v];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone solve
+// x <- b (dense.rs:59), permute by pivots, forward/backward substitution. One workgroup per system.
+template <int VEC>
+__global__ __launch_bounds__(256, 4) void ls_solve_kernel(const double* __restrict__ LU, long mstride, const long long* __restrict__ piv,
+                                                       long pstride, const int* __restrict__ perm /* or null */,
+                                                       double* __restrict__ X, const double* __restrict__ Bv, int n,
+                                                       const int* __restrict__ idx) {
+    extern __shared__ __align__(16) double sm[];
+    double* bs = sm;
+    int* sperm = reinterpret_cast<int*>(sm + n);
+    const int b = idx[blockIdx.x];
+    const int t = threadIdx.x;
+    if (perm) {
+        for (int i = t; i < n; i += 256) bs[i] = Bv[(long)b * n + perm[(long)b * n + i]];
+    } else {
+        // compose the reference's sequential swaps (dense.rs:181-185) into a permutation, one lane, in LDS
+        for (int i = t; i < n; i += 256) sperm[i] = i;
+        __syncthreads();
+        if (t == 0) {
+            const long long* pv = piv + (long)b * pstride;
+            for (int k = 0; k < n; ++k) {
+                const int pk = (int)pv[k];
+                if (pk != k) {
+                    const int tmp = sperm[k];
+                    sperm[k] = sperm[pk];
+                    sperm[pk] = tmp;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < n; i += 256) bs[i] = Bv[(long)b * n + sperm[i]];
+    }
+    __syncthreads();
+    wg_getrs<VEC>(LU + (long)b * mstride, n, bs);
+    for (int i = t; i < n; i += 256) X[(long)b * n + i] = bs[i];
+}
+
+// ------------------------------------------------------------------------------------------------ WRMS
+__global__ __launch_bounds__(256) void wrms_kernel(const double* __restrict__ X, const double* __restrict__ W, double* __restrict__ out,
+                                                   int n, const int* __restrict__ idx) {
+    extern __shared__ __align__(16) double sm[];
+    const int b = idx[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double p = X[(long)b * n + i] * W[(long)b * n + i];
+        sm[i] = p * p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = seq_sum_lds(sm, n);
+}
+
+// ------------------------------------------------------------------------------------------------ fused Newton body
+// delta = -delta; delta = LU^-1 delta; delta *= scale; ee += delta; out = sum_i (delta_i ewt_i)^2 (sequential).
+template <int VEC>
+__global__ __launch_bounds__(256, 4) void newton_iter_kernel(const double* __restrict__ LU, const int* __restrict__ perm, double* __restrict__ delta,
+                                                          double* __restrict__ ee, const double* __restrict__ ewt, int n,
+                                                          const int* __restrict__ idx, const double* __restrict__ scale,
+                                                          double* __restrict__ out) {
+    extern __shared__ __align__(16) double sm[];
+    double* bs = sm;
+    double* sq = sm + n;
+    const int b = idx[blockIdx.x];
+    const int t = threadIdx.x;
+    const long vb = (long)b * n;
+    for (int i = t; i < n; i += 256) bs[i] = -delta[vb + perm[vb + i]];  // neg_mut, then the row permutation
+    __syncthreads();
+    wg_getrs<VEC>(LU + (long)b * n * n, n, bs);
+    const double sc = scale[blockIdx.x];
+    for (int i = t; i < n; i += 256) {
+        const double d = bs[i] * sc;  // ida_ls.rs:406-410 (sc == 1.0 exactly when cjratio == 1)
+        delta[vb + i] = d;
+        ee[vb + i] = ee[vb + i] + d;  // newton.rs:106
+        const double p = d * ewt[vb + i];
+        sq[i] = p * p;
+    }
+    __syncthreads();
+    if (t == 0) out[blockIdx.x] = seq_sum_lds(sq, n);
+}
+
+// ------------------------------------------------------------------------------------------------ tiny (n <= 8)
+__device__ inline void tiny_getrs(const double* __restrict__ a, int n, const long long* __restrict__ pivot, double* b) {
+    for (int k = 0; k < n; ++k) {
+        const int pk = (int)pivot[k];
+        if (pk != k) {
+            const double tmp = b[k];
+            b[k] = b[pk];
+            b[pk] = tmp;
+        }
+    }
+    for (int k = 0; k + 1 < n; ++k) {
+        const double bk = b[k];
+        for (int i = k + 1; i < n; ++i) b[i] -= a[k * n + i] * bk;
+    }
+    for (int k = n - 1; k >= 1; --k) {
+        b[k] /= a[k * n + k];
+        const double bk = b[k];
+        for (int i = 0; i < k; ++i) b[i] -= a[k * n + i] * bk;
+    }
+    b[0] /= a[0];
+}
+
+__global__ void tiny_solve_kernel(const double* LU, long mstride, const long long* piv, long pstride, double* X, const double* Bv,
+                                  int n, const int* idx, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = idx[s];
+    double v[TINY_N];
+    for (int i = 0; i < n; ++i) v[i] = Bv[(long)b * n + i];
+    tiny_getrs(LU + (long)b * mstride, n, piv + (long)b * pstride, v);
+    for (int i = 0; i < n; ++i) X[(long)b * n + i] = v[i];
+}
+
+__global__ void tiny_wrms_kernel(const double* X, const double* W, double* out, int n, const int* idx, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = idx[s];
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double p = X[(long)b * n + i] * W[(long)b * n + i];
+        acc = acc + p * p;
+    }
+    out[s] = acc;
+}
+
+__global__ void tiny_newton_iter_kernel(const double* LU, const long long* piv, double* delta, double* ee, const double* ewt, int n,
+                                        const int* idx, int nsys, const double* scale, double* out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = idx[s];
+    const long vb = (long)b * n;
+    double v[TINY_N];
+    for (int i = 0; i < n; ++i) v[i] = -delta[vb + i];
+    tiny_getrs(LU + (long)b * n * n, n, piv + vb, v);
+    const double sc = scale[s];
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double d = v[i] * sc;
+        delta[vb + i] = d;
+        ee[vb + i] = ee[vb + i] + d;
+        const double p = d * ewt[vb + i];
+        acc = acc + p * p;
+    }
+    out[s] = acc;
+}
+
+}  // namespace idahip

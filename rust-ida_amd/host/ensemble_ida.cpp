@@ -1,0 +1,885 @@
+// libidaens.so -- host-side BDF stepper for an ensemble of independent IVPs (implementation of
+// include/ida_ensemble.h). Mirrors, per system and with the same names, the scalar logic of the reference:
+//   Ida::solve            /root/reference/src/impl_solve.rs:69-376
+//   Ida::step             /root/reference/src/lib.rs:613-711
+//   set_coeffs            /root/reference/src/lib.rs:722-782
+//   nonlinear_solve       /root/reference/src/lib.rs:787-890      (lsetup decision, ss resets)
+//   Newton::solve         /root/reference/crates/nonlinear/src/newton.rs:51-167   (as a batched state machine)
+//   idaNlsConvTest        /root/reference/src/ida_nls.rs:218-266   (host libm pow)
+//   test_error            /root/reference/src/lib.rs:967-1039      (decisions; the norms come from the device)
+//   restore               /root/reference/src/lib.rs:1044-1083
+//   handle_n_flag         /root/reference/src/lib.rs:1120-1244
+//   complete_step         /root/reference/src/impl_complete_step.rs:22-177
+//   get_solution          /root/reference/src/lib.rs:1274-1343      (coefficients; the sums run on the device)
+//   stop_test1/2          /root/reference/src/impl_stop_test.rs:36-211 (no tstop: the reference has no setter)
+// Vectors live on the device; this file talks to it only through include/ida_hip.h. The oracle is NOT used here.
+//
+// Lock-step execution: one "round" is one step attempt (set_coeffs -> predict -> Newton -> error test -> accept or
+// restore) for every system that still has to reach tout; systems diverge freely in h, order, Newton count and
+// lsetup timing, the device calls act on compacted index lists.
+//
+// Deviations from the reference text, identical to the oracle's: Q1 (jac at tn), Q2 (LU failure is a
+// recoverable lsetup failure), Q3 (Newton breaks out on ConvergenceRecover with a current Jacobian), Q4 (Newton
+// ConvergenceRecover is recoverable at step level), Q5 (reset() rescales phi[1] only). Root finding, constraints
+// and tstop are out of scope.
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/ida_ensemble.h"
+
+namespace {
+
+constexpr int MXORDP1 = 6;
+constexpr int MAXORD_DEFAULT = 5;
+constexpr long MXSTEP_DEFAULT = 500;
+constexpr int MXNCF = 10, MXNEF = 10;
+constexpr double EPCON = 0.33;
+constexpr double XRATE = 0.25;
+constexpr int MAXNLSIT = 4;
+constexpr double RATEMAX = 0.9;
+
+enum NlsCode { NLS_SUCCESS = 0, NLS_CONV_RECVR = 1, NLS_LSETUP_RECVR = 2 };
+enum NFlag { NFLAG_NONE = 0, NFLAG_TEST_FAIL = 1, NFLAG_CONV_RECVR = 2, NFLAG_LSETUP_RECVR = 3 };
+enum Phase { PH_IDLE = 0 /* between solve calls */, PH_LOOP_TOP = 1 /* needs the loop-top checks, then a new step */,
+             PH_RETRY = 2 /* inside step()'s attempt loop */ };
+
+struct Sys {
+    // --- Ida scalars (src/lib.rs:89-244)
+    double psi[MXORDP1] = {0}, alpha[MXORDP1] = {0}, beta[MXORDP1] = {0}, sigma[MXORDP1] = {0}, gamma[MXORDP1] = {0};
+    double cvals[MXORDP1] = {0}, dvals[MAXORD_DEFAULT] = {0};
+    int kk = 0, kused = 0, knew = 0, phase = 0, ns = 0;
+    double hin = 0.0, h0u = 0.0, hh = 0.0, hused = 0.0, rr = 0.0;
+    double tretlast = 0.0, cjlast = 0.0, eps_newt = 0.0, tolsf = 1.0;
+    double tn = 0.0;
+    long nst = 0, ncfn = 0, netf = 0;
+    bool setup_done = false;
+    // --- IdaNLProblem / IdaLProblem scalars (src/ida_nls.rs:27-59, src/ida_ls.rs:84-105)
+    double cj = 0.0, cjold = 0.0, cjratio = 0.0, ss = 0.0, oldnrm = 0.0, toldel = 0.0;
+    long nre = 0, nsetups = 0, nje = 0;
+    // --- Newton (crates/nonlinear/src/newton.rs:14-32)
+    bool jcur = false;
+    int curiter = 0;
+    long niters = 0, nconvfails = 0;
+    // --- lock-step bookkeeping
+    int ph = PH_IDLE;
+    double saved_t = 0.0, ck = 0.0;
+    long ncf = 0, nef = 0, nstloc = 0;
+    bool call_lsetup = false;
+    int nls_ret = 0;
+    double phi0nrm = 0.0;  // ||phi[0]||_wrms(ewt) for the next step's tolsf test
+    bool ewt_bad = false;
+    long n_attempts = 0;
+    int status = 0;
+    double tret = 0.0;
+    bool dead = false;  // a fatal IdaError was returned: later solve calls report it again
+};
+
+}  // namespace
+
+struct idaens {
+    idahip_ctx* ctx = nullptr;
+    int n = 0, batch = 0;
+    std::vector<Sys> sys;
+    std::string err;
+    long mxstep = MXSTEP_DEFAULT;
+    int maxord = MAXORD_DEFAULT;
+    long maxncf = MXNCF, maxnef = MXNEF;
+    double epcon = EPCON, hmax_inv = 0.0;
+    int64_t total_rounds = 0;
+    int trace_sys = -1;
+    std::vector<double> trace;
+    // scratch for list calls
+    std::vector<int32_t> idx, ia, ib;
+    std::vector<double> da, db, dc, dd;
+};
+
+namespace {
+
+int efail(idaens* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    e->err = buf;
+    return code;
+}
+
+#define ENS_CALL(e, call)                                                                                   \
+    do {                                                                                                    \
+        int rc__ = (call);                                                                                  \
+        if (rc__ < 0) return efail((e), rc__, "%s failed (%d): %s", #call, rc__, idahip_last_error((e)->ctx)); \
+    } while (0)
+
+double signum(double x) {  // f64::signum
+    if (std::isnan(x)) return x;
+    return std::signbit(x) ? -1.0 : 1.0;
+}
+
+// ---------------------------------------------------------------- set_coeffs scalars (lib.rs:722-766); returns ck
+double set_coeffs(Sys& s) {
+    if (s.hh != s.hused || s.kk != s.kused) s.ns = 0;
+    s.ns = std::min(s.ns + 1, s.kused + 2);
+    if (s.kk + 1 >= s.ns) {
+        s.beta[0] = 1.0;
+        s.alpha[0] = 1.0;
+        double temp1 = s.hh;
+        s.gamma[0] = 0.0;
+        s.sigma[0] = 1.0;
+        for (int i = 1; i <= s.kk; ++i) {
+            const double scalar_i = (double)i;
+            const double temp2 = s.psi[i - 1];
+            s.psi[i - 1] = temp1;
+            s.beta[i] = s.beta[i - 1] * s.psi[i - 1] / temp2;
+            temp1 = temp2 + s.hh;
+            s.alpha[i] = s.hh / temp1;
+            s.sigma[i] = scalar_i * s.sigma[i - 1] * s.alpha[i];
+            s.gamma[i] = s.gamma[i - 1] + s.alpha[i - 1] / s.hh;
+        }
+        s.psi[s.kk] = temp1;
+    }
+    double alphas = 0.0, alpha0 = 0.0;
+    for (int i = 0; i < s.kk; ++i) {
+        const double scalar_i = (double)(i + 1);
+        alphas -= 1.0 / scalar_i;
+        alpha0 -= s.alpha[i];
+    }
+    s.cjlast = s.cj;
+    s.cj = -alphas / s.hh;
+    double ck = std::fabs(s.alpha[s.kk] + alphas - alpha0);
+    ck = std::fmax(ck, s.alpha[s.kk]);
+    return ck;  // the phi-star scaling phi[j] *= beta[j], j = ns..kk, is done by idahip_predict
+}
+
+// ---------------------------------------------------------------- test_error decisions (lib.rs:967-1039)
+bool test_error(Sys& s, double ck, const double* nrm /* enorm_k, enorm_km1, enorm_km2 */, double* err_k_out, double* err_km1_out) {
+    const double scalar_kk = (double)s.kk;
+    const double enorm_k = nrm[0];
+    const double err_k = s.sigma[s.kk] * enorm_k;
+    const double terr_k = err_k * (scalar_kk + 1.0);
+    double err_km1 = 0.0;
+    int knew = s.kk;
+    if (s.kk > 1) {
+        const double enorm_km1 = nrm[1];
+        err_km1 = s.sigma[s.kk - 1] * enorm_km1;
+        const double terr_km1 = scalar_kk * err_km1;
+        if (s.kk > 2) {
+            const double enorm_km2 = nrm[2];
+            const double err_km2 = s.sigma[s.kk - 2] * enorm_km2;
+            const double terr_km2 = (scalar_kk - 1.0) * err_km2;
+            if (std::fmax(terr_km1, terr_km2) <= terr_k) knew = s.kk - 1;
+        } else {
+            if (terr_km1 <= terr_k * 0.5) knew = s.kk - 1;
+        }
+    }
+    s.knew = knew;
+    *err_k_out = err_k;
+    *err_km1_out = err_km1;
+    return (ck * enorm_k) <= 1.0;
+}
+
+// ---------------------------------------------------------------- restore scalars (lib.rs:1044-1083)
+void restore_scalars(Sys& s) {
+    s.tn = s.saved_t;
+    for (int j = 1; j < s.kk + 1; ++j) s.psi[j - 1] = s.psi[j] - s.hh;
+    if (s.ns <= s.kk) {
+        for (int j = s.ns; j <= s.kk; ++j) s.cvals[j - s.ns] = 1.0 / s.beta[j];
+    }
+}
+
+// ---------------------------------------------------------------- handle_n_flag (lib.rs:1120-1244); 0 = predict again
+int handle_n_flag(idaens* e, Sys& s, int nflag, double err_k, double err_km1) {
+    s.phase = 1;
+    if (nflag == NFLAG_TEST_FAIL) {
+        s.nef += 1;
+        s.netf += 1;
+        if (s.nef == 1) {
+            const double err_knew = (s.kk == s.knew) ? err_k : err_km1;
+            s.kk = s.knew;
+            {
+                const double base = 2.0 * err_knew + 0.0001;
+                const double arg = 1.0 / (double)(s.kk + 1);
+                s.rr = 0.9 * std::pow(base, -arg);
+            }
+            s.rr = std::fmax(0.25, std::fmin(0.9, s.rr));
+            s.hh *= s.rr;
+            return 0;
+        } else if (s.nef == 2) {
+            s.kk = s.knew;
+            s.rr = 0.25;
+            s.hh *= s.rr;
+            return 0;
+        } else if (s.nef < e->maxnef) {
+            s.kk = 1;
+            s.rr = 0.25;
+            s.hh *= s.rr;
+            return 0;
+        }
+        return IDAENS_ERR_FAIL;
+    }
+    s.ncf += 1;
+    s.ncfn += 1;
+    s.rr = 0.25;
+    s.hh *= s.rr;
+    if (s.ncf < e->maxncf) return 0;
+    return IDAENS_CONV_FAIL;
+}
+
+// ---------------------------------------------------------------- complete_step scalars (impl_complete_step.rs:22-147)
+void complete_step_scalars(idaens* e, Sys& s, double err_k, double err_km1, double enorm_kp1) {
+    s.nst += 1;
+    const int kdiff = s.kk - s.kused;
+    s.kused = s.kk;
+    s.hused = s.hh;
+    if (s.knew == s.kk - 1 || s.kk == e->maxord) s.phase = 1;
+    if (s.phase == 0) {
+        if (s.nst > 1) {
+            s.kk += 1;
+            double hnew = 2.0 * s.hh;
+            const double tmp = std::fabs(hnew) * e->hmax_inv;
+            if (tmp > 1.0) hnew /= tmp;
+            s.hh = hnew;
+        }
+    } else {
+        enum { LOWER, MAINTAIN, RAISE } action;
+        double err_kp1 = 0.0;
+        if (s.knew == s.kk - 1) {
+            action = LOWER;
+        } else if (s.kk == e->maxord) {
+            action = MAINTAIN;
+        } else if (s.kk + 1 >= s.ns || kdiff == 1) {
+            action = MAINTAIN;
+        } else {
+            const double enorm = enorm_kp1;  // ||ee - phi[kk+1]||
+            err_kp1 = enorm / (double)(s.kk + 2);
+            const double terr_k = (double)(s.kk + 1) * err_k;
+            const double terr_kp1 = (double)(s.kk + 2) * err_kp1;
+            if (s.kk == 1) {
+                action = (terr_kp1 >= 0.5 * terr_k) ? MAINTAIN : RAISE;
+            } else {
+                const double terr_km1 = (double)s.kk * err_km1;
+                if (terr_km1 <= std::fmin(terr_k, terr_kp1)) action = LOWER;
+                else if (terr_kp1 >= terr_k) action = MAINTAIN;
+                else action = RAISE;
+            }
+        }
+        double err_knew;
+        if (action == RAISE) {
+            s.kk += 1;
+            err_knew = err_kp1;
+        } else if (action == LOWER) {
+            s.kk -= 1;
+            err_knew = err_km1;
+        } else {
+            err_knew = err_k;
+        }
+        double hnew = s.hh;
+        {
+            const double base = 2.0 * err_knew + 0.0001;
+            const double arg = -(1.0 / (double)(s.kk + 1));
+            s.rr = std::pow(base, arg);
+        }
+        if (s.rr >= 2.0) {
+            hnew = 2.0 * s.hh;
+            const double tmp = std::fabs(hnew) * e->hmax_inv;
+            if (tmp > 1.0) hnew /= tmp;
+        } else if (s.rr <= 1.0) {
+            s.rr = std::fmax(0.5, std::fmin(s.rr, 0.9));
+            hnew = s.hh * s.rr;
+        }
+        s.hh = hnew;
+    }
+}
+
+// ---------------------------------------------------------------- get_solution coefficients (lib.rs:1274-1317)
+// returns 0 and fills kord/cvals/dvals, or IDAENS_BAD_T
+int get_solution_coeffs(Sys& s, double t, int* kord_out) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double tfuzz = 100.0 * eps * (std::fabs(s.tn) + std::fabs(s.hh)) * signum(s.hh);
+    const double tp = s.tn - s.hused - tfuzz;
+    if ((t - tp) * s.hh < 0.0) return IDAENS_BAD_T;
+    const int kord = (s.kused == 0) ? 1 : s.kused;
+    const double delt = t - s.tn;
+    double c = 1.0, d = 0.0;
+    double gam = delt / s.psi[0];
+    s.cvals[0] = c;
+    for (int j = 1; j <= kord; ++j) {
+        d = d * gam + c / s.psi[j - 1];
+        c = c * gam;
+        gam = (delt + s.psi[j - 1]) / s.psi[j];
+        s.cvals[j] = c;
+        s.dvals[j - 1] = d;
+    }
+    *kord_out = kord;
+    return 0;
+}
+
+struct SolList {  // systems whose yy/yp must be interpolated by the device
+    std::vector<int32_t> idx, kord;
+    std::vector<double> cvals, dvals;
+    void add(int b, const Sys& s, int kord_) {
+        idx.push_back(b);
+        kord.push_back(kord_);
+        cvals.insert(cvals.end(), s.cvals, s.cvals + MXORDP1);
+        dvals.insert(dvals.end(), s.dvals, s.dvals + MAXORD_DEFAULT);
+    }
+};
+
+// get_solution(t) for system b: coefficients now, device sums deferred to the list. Returns 0 or IDAENS_BAD_T.
+int queue_solution(Sys& s, int b, double t, SolList& sl) {
+    int kord = 1;
+    const int rc = get_solution_coeffs(s, t, &kord);
+    if (rc) return rc;
+    sl.add(b, s, kord);
+    return 0;
+}
+
+// ---------------------------------------------------------------- stop tests (impl_stop_test.rs), tstop == None
+int stop_test1(Sys& s, int b, double tout, int itask, SolList& sl) {
+    if (itask == IDAENS_NORMAL) {
+        if (tout == s.tretlast) {
+            s.tretlast = tout;
+            s.tret = tout;
+            return IDAENS_SUCCESS;
+        }
+        if ((s.tn - tout) * s.hh >= 0.0) {
+            const int ier = queue_solution(s, b, tout, sl);
+            if (ier) return ier;
+            s.tretlast = tout;
+            s.tret = tout;
+            return IDAENS_SUCCESS;
+        }
+        return IDAENS_UNFINISHED;  // ContinueSteps
+    }
+    if ((s.tn - s.tretlast) * s.hh > 0.0) {
+        queue_solution(s, b, s.tn, sl);
+        s.tretlast = s.tn;
+        s.tret = s.tn;
+        return IDAENS_SUCCESS;
+    }
+    return IDAENS_UNFINISHED;
+}
+
+int stop_test2(Sys& s, int b, double tout, int itask, SolList& sl) {
+    if (itask == IDAENS_NORMAL) {
+        if ((s.tn - tout) * s.hh >= 0.0) {
+            s.tret = tout;
+            s.tretlast = tout;
+            queue_solution(s, b, tout, sl);
+            return IDAENS_SUCCESS;
+        }
+        return IDAENS_UNFINISHED;
+    }
+    s.tret = s.tn;  // OneStep: yy/yp already hold y(tn)
+    s.tretlast = s.tn;
+    return IDAENS_SUCCESS;
+}
+
+int flush_solutions(idaens* e, SolList& sl) {
+    if (sl.idx.empty()) return 0;
+    ENS_CALL(e, idahip_get_solution(e->ctx, sl.kord.data(), sl.cvals.data(), sl.dvals.data(), sl.idx.data(), (int)sl.idx.size()));
+    sl = SolList();
+    return 0;
+}
+
+// ---------------------------------------------------------------- the batched Newton solve (newton.rs:51-167)
+// `act`: systems taking a step attempt this round, with s.call_lsetup decided. Sets s.nls_ret.
+int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
+    std::vector<Sys>& S = e->sys;
+    std::vector<int32_t> R(act), I, C, L;
+    std::vector<uint8_t> jbad(e->batch, 0);
+    std::vector<double> tn, cj, sc, nrm;
+    std::vector<int32_t> info;
+    while (!R.empty() || !I.empty()) {
+        if (!R.empty()) {
+            tn.clear(); cj.clear();
+            for (int b : R) { tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
+            ENS_CALL(e, idahip_nls_sys(e->ctx, tn.data(), cj.data(), 1, R.data(), (int)R.size()));  // sys(y0), y <- y0 = 0
+            for (int b : R) S[b].nre += 1;
+            L.clear(); tn.clear(); cj.clear();
+            for (int b : R)
+                if (S[b].call_lsetup) { L.push_back(b); tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
+            if (!L.empty()) {
+                info.assign(L.size(), 0);
+                ENS_CALL(e, idahip_nls_lsetup(e->ctx, tn.data(), cj.data(), info.data(), L.data(), (int)L.size()));
+                for (size_t q = 0; q < L.size(); ++q) {
+                    Sys& s = S[L[q]];
+                    s.nsetups += 1;  // idaNlsLSetup (ida_nls.rs:168)
+                    s.nje += 1;      // idaLsSetup   (ida_ls.rs:250)
+                    s.jcur = true;
+                    s.cjold = s.cj;  // ida_nls.rs:177-179
+                    s.cjratio = 1.0;
+                    s.ss = 20.0;
+                    s.nls_ret = info[q] ? NLS_LSETUP_RECVR : NLS_SUCCESS;
+                }
+            }
+            for (int b : R) {
+                Sys& s = S[b];
+                if (s.call_lsetup && s.nls_ret == NLS_LSETUP_RECVR) {
+                    s.nconvfails += 1;  // jcur is true: no retry (newton.rs:146-153 with Q3)
+                    continue;
+                }
+                s.curiter = 0;
+                I.push_back(b);
+            }
+            R.clear();
+        }
+        if (I.empty()) break;
+        sc.clear();
+        for (int b : I) sc.push_back(S[b].cjratio != 1.0 ? 2.0 / (1.0 + S[b].cjratio) : 1.0);  // ida_ls.rs:406-410
+        nrm.assign(I.size(), 0.0);
+        ENS_CALL(e, idahip_newton_iter(e->ctx, sc.data(), nrm.data(), I.data(), (int)I.size()));
+        C.clear();
+        for (size_t q = 0; q < I.size(); ++q) {
+            const int b = I[q];
+            Sys& s = S[b];
+            s.niters += 1;
+            // idaNlsConvTest (ida_nls.rs:218-266)
+            const double delnrm = nrm[q];
+            const int m = s.curiter;
+            bool converged = false;
+            int ret = NLS_SUCCESS;
+            if (m == 0) {
+                s.oldnrm = delnrm;
+                if (delnrm <= 0.0001 * s.toldel) converged = true;
+            } else {
+                const double base = delnrm / s.oldnrm;
+                const double arg = 1.0 / (double)m;
+                const double rate = std::pow(base, arg);
+                if (rate > RATEMAX) ret = NLS_CONV_RECVR;
+                else s.ss = rate / (1.0 - rate);
+            }
+            if (ret == NLS_SUCCESS && !converged && s.ss * delnrm <= s.eps_newt) converged = true;
+            if (ret == NLS_SUCCESS && converged) {
+                s.jcur = false;
+                s.nls_ret = NLS_SUCCESS;
+                continue;
+            }
+            if (ret == NLS_SUCCESS) {
+                s.curiter += 1;
+                if (s.curiter >= MAXNLSIT) ret = NLS_CONV_RECVR;
+            }
+            if (ret == NLS_SUCCESS) {
+                C.push_back(b);  // sys(y) then iterate again
+                continue;
+            }
+            // ConvergenceRecover
+            if (!s.jcur) {
+                s.nconvfails += 1;
+                s.call_lsetup = true;
+                jbad[b] = 1;
+                R.push_back(b);
+            } else {
+                s.nconvfails += 1;
+                s.nls_ret = NLS_CONV_RECVR;
+            }
+        }
+        if (!C.empty()) {
+            tn.clear(); cj.clear();
+            for (int b : C) { tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
+            ENS_CALL(e, idahip_nls_sys(e->ctx, tn.data(), cj.data(), 0, C.data(), (int)C.size()));
+            for (int b : C) S[b].nre += 1;
+        }
+        I.swap(C);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- one lock-step round over `act`
+int attempt_round(idaens* e, std::vector<int32_t>& act, double tout, int itask, SolList& sl) {
+    std::vector<Sys>& S = e->sys;
+    const int na = (int)act.size();
+    // --- step() prologue + set_coeffs + tn += hh (lib.rs:619-653)
+    std::vector<int32_t> kkns(2 * (size_t)na);
+    std::vector<double> beta(MXORDP1 * (size_t)na), gamma(MXORDP1 * (size_t)na);
+    for (int q = 0; q < na; ++q) {
+        Sys& s = S[act[q]];
+        if (s.ph == PH_LOOP_TOP) {  // entering step()
+            s.saved_t = s.tn;
+            if (s.nst == 0) {
+                s.kk = 1;
+                s.kused = 0;
+                s.hused = 0.0;
+                s.psi[0] = s.hh;
+                s.cj = 1.0 / s.hh;
+                s.phase = 0;
+                s.ns = 0;
+            }
+            s.ncf = 0;
+            s.nef = 0;
+            s.ph = PH_RETRY;
+        }
+        s.n_attempts += 1;
+        s.ck = set_coeffs(s);
+        s.tn += s.hh;
+        kkns[2 * q] = s.kk;
+        kkns[2 * q + 1] = s.ns;
+        for (int j = 0; j < MXORDP1; ++j) {
+            beta[MXORDP1 * q + j] = s.beta[j];
+            gamma[MXORDP1 * q + j] = s.gamma[j];
+        }
+        // nonlinear_solve prologue (lib.rs:792-812)
+        s.call_lsetup = false;
+        if (s.nst == 0) {
+            s.cjold = s.cj;
+            s.ss = 20.0;
+            s.call_lsetup = true;
+        }
+        s.cjratio = s.cj / s.cjold;
+        const double temp1 = (1.0 - XRATE) / (1.0 + XRATE);
+        const double temp2 = 1.0 / temp1;
+        if (s.cjratio < temp1 || s.cjratio > temp2) s.call_lsetup = true;
+        if (s.cj != s.cjlast) s.ss = 100.0;
+        s.nls_ret = NLS_SUCCESS;
+    }
+    ENS_CALL(e, idahip_predict(e->ctx, kkns.data(), beta.data(), gamma.data(), act.data(), na));
+
+    // --- Newton
+    int rc = newton_solve_batched(e, act);
+    if (rc) return rc;
+
+    // --- final yy/yp + error-test norms (lib.rs:845-849, 983-1004; impl_complete_step.rs:74-77)
+    std::vector<double> cj(na), norms(4 * (size_t)na);
+    std::vector<int32_t> kk(na);
+    for (int q = 0; q < na; ++q) {
+        cj[q] = S[act[q]].cj;
+        kk[q] = S[act[q]].kk;
+    }
+    ENS_CALL(e, idahip_post_newton(e->ctx, cj.data(), kk.data(), norms.data(), act.data(), na));
+
+    // --- decisions
+    std::vector<int32_t> rest_idx, rest_kkns, done_idx, done_kused, reset_idx;
+    std::vector<double> rest_cvals, done_ck, reset_fac;
+    std::vector<int32_t> next;
+    for (int q = 0; q < na; ++q) {
+        const int b = act[q];
+        Sys& s = S[b];
+        int nflag = NFLAG_NONE;
+        double err_k = 0.0, err_km1 = 0.0;
+        if (s.nls_ret == NLS_SUCCESS) {
+            if (!test_error(s, s.ck, &norms[4 * q], &err_k, &err_km1)) nflag = NFLAG_TEST_FAIL;
+        } else if (s.nls_ret == NLS_CONV_RECVR) {
+            nflag = NFLAG_CONV_RECVR;
+        } else {
+            nflag = NFLAG_LSETUP_RECVR;
+        }
+        if (nflag != NFLAG_NONE) {
+            // restore (with the kk/ns/beta of this attempt), then handle_n_flag
+            const int kk_att = s.kk, ns_att = s.ns;
+            restore_scalars(s);
+            if (ns_att <= kk_att) {
+                rest_idx.push_back(b);
+                rest_kkns.push_back(kk_att);
+                rest_kkns.push_back(ns_att);
+                rest_cvals.insert(rest_cvals.end(), s.cvals, s.cvals + MXORDP1);
+            }
+            const int kflag = handle_n_flag(e, s, nflag, err_k, err_km1);
+            if (kflag != 0) {  // step failed for good: Ida::solve's failed-step path (impl_solve.rs:300-313)
+                if (queue_solution(s, b, s.tn, sl) == 0) {
+                    s.tret = s.tn;
+                    s.tretlast = s.tn;
+                }
+                s.status = kflag;
+                s.dead = true;
+                s.ph = PH_IDLE;
+                continue;
+            }
+            if (s.nst == 0) {  // reset(): psi[0] = hh; phi[1] *= rr  (Q5)
+                s.psi[0] = s.hh;
+                reset_idx.push_back(b);
+                reset_fac.push_back(s.rr);
+            }
+            next.push_back(b);  // predict again
+            continue;
+        }
+        // accepted: complete_step (scalars now, vectors below), ee *= ck
+        complete_step_scalars(e, s, err_k, err_km1, norms[4 * q + 3]);
+        done_idx.push_back(b);
+        done_kused.push_back(s.kused);
+        done_ck.push_back(s.ck);
+        if (b == e->trace_sys) {
+            e->trace.push_back(s.tn);
+            e->trace.push_back(s.hused);
+            e->trace.push_back((double)s.kused);
+        }
+    }
+    if (!rest_idx.empty())
+        ENS_CALL(e, idahip_restore(e->ctx, rest_kkns.data(), rest_cvals.data(), rest_idx.data(), (int)rest_idx.size()));
+    if (!reset_idx.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, reset_fac.data(), reset_idx.data(), (int)reset_idx.size()));
+    if (!done_idx.empty()) {
+        std::vector<double> p0(done_idx.size());
+        std::vector<int32_t> bad(done_idx.size());
+        ENS_CALL(e, idahip_complete_step(e->ctx, done_kused.data(), done_ck.data(), e->maxord, p0.data(), bad.data(), done_idx.data(),
+                                         (int)done_idx.size()));
+        for (size_t q = 0; q < done_idx.size(); ++q) {
+            const int b = done_idx[q];
+            Sys& s = S[b];
+            s.phi0nrm = p0[q];
+            s.ewt_bad = bad[q] != 0;
+            s.nstloc += 1;
+            s.ph = PH_LOOP_TOP;
+            const int istate = stop_test2(s, b, tout, itask, sl);
+            if (istate != IDAENS_UNFINISHED) {
+                s.status = istate;
+                s.ph = PH_IDLE;
+            } else {
+                next.push_back(b);
+            }
+        }
+    }
+    act.swap(next);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const double* hYP0) {
+    if (!out || !ctx || !hYY0 || !hYP0) return -1;
+    idaens* e = new idaens();
+    e->ctx = ctx;
+    e->n = idahip_n(ctx);
+    e->batch = idahip_batch(ctx);
+    e->sys.resize(e->batch);
+    // Ida::new (lib.rs:291-293): phi[0] = yy0, phi[1] = yp0; yy/yp start as yy0/yp0 (ida_nls.rs:83-84)
+    int rc = idahip_upload(ctx, IDAHIP_F_PHI0, 0, e->batch, hYY0);
+    if (!rc) rc = idahip_upload(ctx, (idahip_field)(IDAHIP_F_PHI0 + 1), 0, e->batch, hYP0);
+    if (!rc) rc = idahip_upload(ctx, IDAHIP_F_YY, 0, e->batch, hYY0);
+    if (!rc) rc = idahip_upload(ctx, IDAHIP_F_YP, 0, e->batch, hYP0);
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return 0;
+}
+
+int idaens_destroy(idaens* e) {
+    delete e;
+    return 0;
+}
+
+const char* idaens_last_error(const idaens* e) { return e ? e->err.c_str() : "null"; }
+
+int idaens_set_max_num_steps(idaens* e, long mxstep) {
+    if (!e || mxstep < 0) return -1;
+    e->mxstep = mxstep;
+    return 0;
+}
+int idaens_set_max_ord(idaens* e, int maxord) {
+    if (!e || maxord < 1 || maxord > MAXORD_DEFAULT) return -1;
+    e->maxord = maxord;
+    return 0;
+}
+
+int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds) {
+    if (!e || !hTret || !hStatus) return -1;
+    const double eps = std::numeric_limits<double>::epsilon();
+    std::vector<Sys>& S = e->sys;
+    SolList sl;
+    std::vector<int32_t> act;
+
+    // ---- first-call block for systems that have not started (impl_solve.rs:84-173)
+    {
+        std::vector<int32_t> fresh;
+        for (int b = 0; b < e->batch; ++b)
+            if (S[b].ph == PH_IDLE && S[b].nst == 0 && !S[b].setup_done && !S[b].dead) fresh.push_back(b);
+        if (!fresh.empty()) {
+            // initial_setup's ewt_set(phi[0]) (lib.rs:537-545), ||phi[1]|| for the h0 heuristic (impl_solve.rs:122-126)
+            // and ||phi[0]|| for the first tolsf test (impl_solve.rs:289-295)
+            std::vector<double> ypnorm(fresh.size()), p0nrm(fresh.size());
+            ENS_CALL(e, idahip_init_first(e->ctx, ypnorm.data(), p0nrm.data(), fresh.data(), (int)fresh.size()));
+            std::vector<int32_t> ok;
+            std::vector<double> fac;
+            for (size_t q = 0; q < fresh.size(); ++q) {
+                Sys& s = S[fresh[q]];
+                const double tdist = std::fabs(tout - s.tn);
+                const double troundoff = 2.0 * eps * (std::fabs(s.tn) + std::fabs(tout));
+                if (tdist == 0.0 || tdist < troundoff) {
+                    s.status = IDAENS_ILL_INPUT;  // "tout too close to t0 to start integration"
+                    s.tret = s.tn;
+                    continue;
+                }
+                s.setup_done = true;
+                s.hh = s.hin;
+                if (s.hh == 0.0) {
+                    s.hh = 0.001 * tdist;
+                    if (ypnorm[q] > 2.0 / s.hh) s.hh = 0.5 / ypnorm[q];  // Q7 kept (impl_solve.rs:127)
+                    if (tout < s.tn) s.hh = -s.hh;
+                }
+                const double rh = std::fabs(s.hh) * e->hmax_inv;
+                if (rh > 1.0) s.hh /= rh;
+                s.h0u = s.hh;
+                s.kk = 0;
+                s.kused = 0;
+                s.eps_newt = e->epcon;
+                s.toldel = 0.0001 * s.eps_newt;
+                s.phi0nrm = p0nrm[q];
+                ok.push_back(fresh[q]);
+                fac.push_back(s.hh);
+            }
+            if (!ok.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, fac.data(), ok.data(), (int)ok.size()));  // phi[1] = hh*y'
+        }
+    }
+
+    // ---- per-system entry: stop tests for started systems, then collect who steps (impl_solve.rs:179-241)
+    for (int b = 0; b < e->batch; ++b) {
+        Sys& s = S[b];
+        if (s.ph != PH_IDLE) {  // left mid-flight by a round limit: resume
+            act.push_back(b);
+            continue;
+        }
+        if (s.dead || !s.setup_done) continue;  // earlier fatal error / ILL_INPUT at the first call: status is sticky
+        s.nstloc = 0;
+        if (s.nst > 0) {
+            const int istate = stop_test1(s, b, tout, itask, sl);
+            if (istate != IDAENS_UNFINISHED) {
+                s.status = istate;
+                if (istate < 0) s.dead = true;
+                continue;
+            }
+        }
+        s.ph = PH_LOOP_TOP;
+        act.push_back(b);
+    }
+
+    // ---- main loop
+    long rounds = 0;
+    while (!act.empty()) {
+        if (max_rounds > 0 && rounds >= max_rounds) break;
+        // loop-top checks for systems starting a new step (impl_solve.rs:246-297)
+        std::vector<int32_t> go;
+        for (int b : act) {
+            Sys& s = S[b];
+            if (s.ph == PH_LOOP_TOP) {
+                if (e->mxstep > 0 && s.nstloc >= e->mxstep) {
+                    s.tret = s.tn;
+                    s.tretlast = s.tn;
+                    s.status = IDAENS_TOO_MUCH_WORK;  // recoverable for the caller: the next solve call continues
+                    s.ph = PH_IDLE;
+                    continue;
+                }
+                if (s.nst > 0 && s.ewt_bad) {
+                    queue_solution(s, b, s.tn, sl);
+                    s.tret = s.tn;
+                    s.tretlast = s.tn;
+                    s.status = IDAENS_ILL_INPUT;
+                    s.dead = true;
+                    s.ph = PH_IDLE;
+                    continue;
+                }
+                s.tolsf = eps * s.phi0nrm;
+                if (s.tolsf > 1.0) {
+                    s.tolsf *= 10.0;
+                    s.tret = s.tn;
+                    s.tretlast = s.tn;
+                    if (s.nst > 0) queue_solution(s, b, s.tn, sl);
+                    s.status = IDAENS_TOO_MUCH_ACC;
+                    s.dead = true;
+                    s.ph = PH_IDLE;
+                    continue;
+                }
+            }
+            go.push_back(b);
+        }
+        act.swap(go);
+        if (act.empty()) break;
+        int rc = attempt_round(e, act, tout, itask, sl);
+        if (rc) return rc;
+        rounds += 1;
+        e->total_rounds += 1;
+    }
+    int rc = flush_solutions(e, sl);
+    if (rc) return rc;
+    for (int b = 0; b < e->batch; ++b) {
+        Sys& s = S[b];
+        if (s.ph != PH_IDLE) {
+            hStatus[b] = IDAENS_UNFINISHED;
+            hTret[b] = s.tn;
+        } else {
+            hStatus[b] = s.status;
+            hTret[b] = s.tret;
+        }
+    }
+    return 0;
+}
+
+int idaens_get_counter(const idaens* e, int which, int64_t* out) {
+    if (!e || !out) return -1;
+    for (int b = 0; b < e->batch; ++b) {
+        const Sys& s = e->sys[b];
+        int64_t v = 0;
+        switch (which) {
+            case IDAENS_C_NST: v = s.nst; break;
+            case IDAENS_C_NRE: v = s.nre; break;
+            case IDAENS_C_NJE: v = s.nje; break;
+            case IDAENS_C_NSETUPS: v = s.nsetups; break;
+            case IDAENS_C_NNI: v = s.niters; break;  // Q11: nni is the Newton counter (ida_io.rs:84-88)
+            case IDAENS_C_NETF: v = s.netf; break;
+            case IDAENS_C_NCFN: v = s.ncfn; break;
+            case IDAENS_C_NATTEMPTS: v = s.n_attempts; break;
+            case IDAENS_C_NLS_NCONVFAILS: v = s.nconvfails; break;
+            case IDAENS_C_KUSED: v = s.kused; break;
+            case IDAENS_C_KK: v = s.kk; break;
+            default: return -2;
+        }
+        out[b] = v;
+    }
+    return 0;
+}
+
+int idaens_get_real(const idaens* e, int which, double* out) {
+    if (!e || !out) return -1;
+    for (int b = 0; b < e->batch; ++b) {
+        const Sys& s = e->sys[b];
+        switch (which) {
+            case IDAENS_R_TN: out[b] = s.tn; break;
+            case IDAENS_R_HUSED: out[b] = s.hused; break;
+            case IDAENS_R_HH: out[b] = s.hh; break;
+            case IDAENS_R_H0U: out[b] = s.h0u; break;
+            case IDAENS_R_TOLSF: out[b] = s.tolsf; break;
+            default: return -2;
+        }
+    }
+    return 0;
+}
+
+int idaens_get_yy(idaens* e, double* hYY) {
+    if (!e) return -1;
+    ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YY, 0, e->batch, hYY));
+    return 0;
+}
+int idaens_get_yp(idaens* e, double* hYP) {
+    if (!e) return -1;
+    ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YP, 0, e->batch, hYP));
+    return 0;
+}
+
+int64_t idaens_total_newton_iters(const idaens* e) {
+    int64_t t = 0;
+    if (e)
+        for (const Sys& s : e->sys) t += s.niters;
+    return t;
+}
+int64_t idaens_total_rounds(const idaens* e) { return e ? e->total_rounds : 0; }
+
+int idaens_trace_system(idaens* e, int sys) {
+    if (!e || sys < -1 || sys >= e->batch) return -1;
+    e->trace_sys = sys;
+    e->trace.clear();
+    return 0;
+}
+long idaens_trace_len(const idaens* e) { return e ? (long)(e->trace.size() / 3) : 0; }
+int idaens_trace_get(const idaens* e, double* out) {
+    if (!e || !out) return -1;
+    for (size_t i = 0; i < e->trace.size(); ++i) out[i] = e->trace[i];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+"""ctypes bindings of libidahip.so (include/ida_hip.h) and libidaens.so (include/ida_ensemble.h).
+
+The HIP path is the only path: importing this package without the built libraries raises (there is no CPU
+fallback and the CPU oracle is never imported from here). Build with `python __graft_entry__.py` or
+`make -C rust-ida_amd/csrc && make -C rust-ida_amd/host`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_HIP = os.path.join(_PKG, "csrc", "libidahip.so")
+LIB_ENS = os.path.join(_PKG, "host", "libidaens.so")
+
+dp = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+ROBERTS, LORENZ63, LINEAR_DENSE, HEAT1D = 0, 1, 2, 3
+KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, "heat1d": HEAT1D}
+F_YY, F_YP, F_YYPREDICT, F_YPPREDICT, F_EWT, F_EE, F_DELTA, F_SAVRES, F_PHI0 = range(9)
+K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE = range(6)
+K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve"]
+
+# symbols declared in include/ida_hip.h / include/ida_ensemble.h (checked by tests/test_abi_symbols.py)
+HIP_SYMBOLS = [
+    "idahip_create", "idahip_destroy", "idahip_last_error", "idahip_sync", "idahip_n", "idahip_batch", "idahip_set_tolerances",
+    "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_upload", "idahip_download", "idahip_download_lu",
+    "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
+    "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
+    "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution",
+    "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset",
+]
+ENS_SYMBOLS = [
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_solve",
+    "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_total_newton_iters",
+    "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
+]
+
+_libs = None
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _p(a, t=dp):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def load():
+    """Load both shared libraries; raises OSError if the HIP extension has not been built."""
+    global _libs
+    if _libs is not None:
+        return _libs
+    for p in (LIB_HIP, LIB_ENS):
+        if not os.path.exists(p):
+            raise OSError("%s is missing: the HIP extension is not built (run `python __graft_entry__.py`); "
+                          "there is no CPU fallback" % p)
+    H = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
+    E = C.CDLL(LIB_ENS)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    H.idahip_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp]
+    H.idahip_destroy.argtypes = [vp]
+    H.idahip_last_error.argtypes = [vp]
+    H.idahip_last_error.restype = C.c_char_p
+    H.idahip_sync.argtypes = [vp]
+    H.idahip_n.argtypes = [vp]
+    H.idahip_batch.argtypes = [vp]
+    H.idahip_set_tolerances.argtypes = [vp, cd, dp, ci]
+    H.idahip_set_problem_params.argtypes = [vp, ci, ci, dp, ci]
+    H.idahip_set_linear_dense.argtypes = [vp, ci, ci, dp, dp, dp]
+    H.idahip_upload.argtypes = [vp, ci, ci, ci, dp]
+    H.idahip_download.argtypes = [vp, ci, ci, ci, dp]
+    H.idahip_download_lu.argtypes = [vp, ci, dp, i64p]
+    H.idahip_dev_alloc.argtypes = [vp, C.c_size_t]
+    H.idahip_dev_alloc.restype = vp
+    H.idahip_dev_free.argtypes = [vp, vp]
+    H.idahip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    H.idahip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    H.idahip_ls_setup.argtypes = [vp, vp, vp, i32p, i32p, ci]
+    H.idahip_ls_solve.argtypes = [vp, vp, vp, vp, vp, cd, i32p, ci]
+    H.idahip_wrms.argtypes = [vp, vp, vp, dp, i32p, ci]
+    H.idahip_nls_sys.argtypes = [vp, dp, dp, ci, i32p, ci]
+    H.idahip_nls_lsetup.argtypes = [vp, dp, dp, i32p, i32p, ci]
+    H.idahip_newton_iter.argtypes = [vp, dp, dp, i32p, ci]
+    H.idahip_init_first.argtypes = [vp, dp, dp, i32p, ci]
+    H.idahip_scale_phi1.argtypes = [vp, dp, i32p, ci]
+    H.idahip_predict.argtypes = [vp, i32p, dp, dp, i32p, ci]
+    H.idahip_post_newton.argtypes = [vp, dp, i32p, dp, i32p, ci]
+    H.idahip_restore.argtypes = [vp, i32p, dp, i32p, ci]
+    H.idahip_complete_step.argtypes = [vp, i32p, dp, ci, dp, i32p, i32p, ci]
+    H.idahip_get_solution.argtypes = [vp, i32p, dp, dp, i32p, ci]
+    H.idahip_timing_enable.argtypes = [vp, ci]
+    H.idahip_timing_get.argtypes = [vp, ci, dp, i64p, i64p]
+    H.idahip_timing_reset.argtypes = [vp]
+    E.idaens_create.argtypes = [C.POINTER(vp), vp, dp, dp]
+    E.idaens_destroy.argtypes = [vp]
+    E.idaens_last_error.argtypes = [vp]
+    E.idaens_last_error.restype = C.c_char_p
+    E.idaens_set_max_num_steps.argtypes = [vp, C.c_long]
+    E.idaens_set_max_ord.argtypes = [vp, ci]
+    E.idaens_solve.argtypes = [vp, cd, ci, dp, i32p, C.c_long]
+    E.idaens_get_counter.argtypes = [vp, ci, i64p]
+    E.idaens_get_real.argtypes = [vp, ci, dp]
+    E.idaens_get_yy.argtypes = [vp, dp]
+    E.idaens_get_yp.argtypes = [vp, dp]
+    E.idaens_total_newton_iters.argtypes = [vp]
+    E.idaens_total_newton_iters.restype = C.c_int64
+    E.idaens_total_rounds.argtypes = [vp]
+    E.idaens_total_rounds.restype = C.c_int64
+    E.idaens_trace_system.argtypes = [vp, ci]
+    E.idaens_trace_len.argtypes = [vp]
+    E.idaens_trace_len.restype = C.c_long
+    E.idaens_trace_get.argtypes = [vp, dp]
+    _libs = (H, E)
+    return _libs
+
+
+class IdaHipError(RuntimeError):
+    pass
+
+
+class Ctx:
+    """One ensemble context on one device (idahip_ctx)."""
+
+    def __init__(self, kind, n, batch, device=0, stream=None):
+        self.H, self.E = load()
+        self.n, self.batch = int(n), int(batch)
+        self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
+        h = C.c_void_p()
+        rc = self.H.idahip_create(C.byref(h), int(device), self.n, self.batch, self.kind, stream)
+        if rc != 0 or not h.value:
+            raise IdaHipError("idahip_create failed (%d) -- is a GPU visible?" % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.H.idahip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise IdaHipError("%s failed (%d): %s" % (what, rc, self.H.idahip_last_error(self.h).decode()))
+        return rc
+
+    def all_idx(self):
+        return np.arange(self.batch, dtype=np.int32)
+
+    # --- setup
+    def set_tolerances(self, rtol, atol):
+        a = _f64(np.atleast_1d(atol))
+        self._chk(self.H.idahip_set_tolerances(self.h, float(rtol), _p(a), a.size), "set_tolerances")
+
+    def set_problem_params(self, params, first=0):
+        p = _f64(params).reshape(-1, _f64(params).shape[-1] if np.ndim(params) > 1 else 1)
+        self._chk(self.H.idahip_set_problem_params(self.h, first, p.shape[0], _p(p), p.shape[1]), "set_problem_params")
+
+    def set_linear_dense(self, A, B, c, first=0):
+        """A, B: [count][n][n] stored column-major per system, i.e. A[s, j, i] = A_s(i, j); c: [count][n]."""
+        A, B, c = _f64(A), _f64(B), _f64(c)
+        self._chk(self.H.idahip_set_linear_dense(self.h, first, A.shape[0], _p(A), _p(B), _p(c)), "set_linear_dense")
+
+    def upload(self, field, arr, first=0):
+        a = _f64(arr).reshape(-1, self.n)
+        self._chk(self.H.idahip_upload(self.h, field, first, a.shape[0], _p(a)), "upload")
+
+    def download(self, field, first=0, count=None):
+        count = self.batch - first if count is None else count
+        out = np.empty((count, self.n))
+        self._chk(self.H.idahip_download(self.h, field, first, count, _p(out)), "download")
+        return out
+
+    def download_lu(self, sys):
+        lu = np.empty(self.n * self.n)
+        piv = np.empty(self.n, dtype=np.int64)
+        self._chk(self.H.idahip_download_lu(self.h, sys, _p(lu), _p(piv, i64p)), "download_lu")
+        return lu.reshape(self.n, self.n).T.copy(), piv  # logical (row, col) view of the column-major buffer
+
+    # --- device buffers for the stand-alone LSolver calls
+    def dev_array(self, host):
+        host = np.ascontiguousarray(host)
+        d = self.H.idahip_dev_alloc(self.h, host.nbytes)
+        if not d:
+            raise IdaHipError("device allocation of %d bytes failed" % host.nbytes)
+        self._chk(self.H.idahip_memcpy_h2d(self.h, d, host.ctypes.data_as(C.c_void_p), host.nbytes), "h2d")
+        return d
+
+    def dev_empty(self, nbytes):
+        d = self.H.idahip_dev_alloc(self.h, nbytes)
+        if not d:
+            raise IdaHipError("device allocation of %d bytes failed" % nbytes)
+        return d
+
+    def to_host(self, d, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.H.idahip_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), d, out.nbytes), "d2h")
+        return out
+
+    def dev_free(self, d):
+        self.H.idahip_dev_free(self.h, d)
+
+    # --- LSolver
+    def ls_setup(self, dA, dPiv, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        info = np.zeros(idx.size, dtype=np.int32)
+        rc = self._chk(self.H.idahip_ls_setup(self.h, dA, dPiv, _p(info, i32p), _p(idx, i32p), idx.size), "ls_setup")
+        return rc, info
+
+    def ls_solve(self, dLU, dPiv, dX, dB, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        self._chk(self.H.idahip_ls_solve(self.h, dLU, dPiv, dX, dB, 0.0, _p(idx, i32p), idx.size), "ls_solve")
+        self._chk(self.H.idahip_sync(self.h), "sync")
+
+    def wrms(self, dX, dW, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        out = np.zeros(idx.size)
+        self._chk(self.H.idahip_wrms(self.h, dX, dW, _p(out), _p(idx, i32p), idx.size), "wrms")
+        return out
+
+    # --- NLProblem
+    def nls_sys(self, tn, cj, reset_ee, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        tn, cj = _f64(np.broadcast_to(tn, idx.shape)), _f64(np.broadcast_to(cj, idx.shape))
+        self._chk(self.H.idahip_nls_sys(self.h, _p(tn), _p(cj), int(reset_ee), _p(idx, i32p), idx.size), "nls_sys")
+
+    def nls_lsetup(self, tn, cj, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        tn, cj = _f64(np.broadcast_to(tn, idx.shape)), _f64(np.broadcast_to(cj, idx.shape))
+        info = np.zeros(idx.size, dtype=np.int32)
+        rc = self._chk(self.H.idahip_nls_lsetup(self.h, _p(tn), _p(cj), _p(info, i32p), _p(idx, i32p), idx.size), "nls_lsetup")
+        return rc, info
+
+    def newton_iter(self, scale, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        scale = _f64(np.broadcast_to(scale, idx.shape))
+        out = np.zeros(idx.size)
+        self._chk(self.H.idahip_newton_iter(self.h, _p(scale), _p(out), _p(idx, i32p), idx.size), "newton_iter")
+        return out
+
+    # --- stepper vector ops
+    def init_first(self, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        a, b = np.zeros(idx.size), np.zeros(idx.size)
+        self._chk(self.H.idahip_init_first(self.h, _p(a), _p(b), _p(idx, i32p), idx.size), "init_first")
+        return a, b
+
+    def scale_phi1(self, fac, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        fac = _f64(np.broadcast_to(fac, idx.shape))
+        self._chk(self.H.idahip_scale_phi1(self.h, _p(fac), _p(idx, i32p), idx.size), "scale_phi1")
+
+    def predict(self, kk, ns, beta, gamma, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        kkns = _i32(np.stack([np.broadcast_to(kk, idx.shape), np.broadcast_to(ns, idx.shape)], axis=1))
+        beta = _f64(np.broadcast_to(beta, (idx.size, 6)))
+        gamma = _f64(np.broadcast_to(gamma, (idx.size, 6)))
+        self._chk(self.H.idahip_predict(self.h, _p(kkns, i32p), _p(beta), _p(gamma), _p(idx, i32p), idx.size), "predict")
+
+    def post_newton(self, cj, kk, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        cj = _f64(np.broadcast_to(cj, idx.shape))
+        kk = _i32(np.broadcast_to(kk, idx.shape))
+        out = np.zeros((idx.size, 4))
+        self._chk(self.H.idahip_post_newton(self.h, _p(cj), _p(kk, i32p), _p(out), _p(idx, i32p), idx.size), "post_newton")
+        return out
+
+    def restore(self, kk, ns, cvals, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        kkns = _i32(np.stack([np.broadcast_to(kk, idx.shape), np.broadcast_to(ns, idx.shape)], axis=1))
+        cvals = _f64(np.broadcast_to(cvals, (idx.size, 6)))
+        self._chk(self.H.idahip_restore(self.h, _p(kkns, i32p), _p(cvals), _p(idx, i32p), idx.size), "restore")
+
+    def complete_step(self, kused, ck, maxord=5, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        kused = _i32(np.broadcast_to(kused, idx.shape))
+        ck = _f64(np.broadcast_to(ck, idx.shape))
+        nrm = np.zeros(idx.size)
+        bad = np.zeros(idx.size, dtype=np.int32)
+        self._chk(self.H.idahip_complete_step(self.h, _p(kused, i32p), _p(ck), int(maxord), _p(nrm), _p(bad, i32p), _p(idx, i32p),
+                                              idx.size), "complete_step")
+        return nrm, bad
+
+    def get_solution(self, kord, cvals, dvals, idx=None):
+        idx = self.all_idx() if idx is None else _i32(idx)
+        kord = _i32(np.broadcast_to(kord, idx.shape))
+        cvals = _f64(np.broadcast_to(cvals, (idx.size, 6)))
+        dvals = _f64(np.broadcast_to(dvals, (idx.size, 5)))
+        self._chk(self.H.idahip_get_solution(self.h, _p(kord, i32p), _p(cvals), _p(dvals), _p(idx, i32p), idx.size), "get_solution")
+
+    # --- measurement
+    def timing(self, on):
+        self.H.idahip_timing_enable(self.h, int(on))
+
+    def timing_reset(self):
+        self.H.idahip_timing_reset(self.h)
+
+    def timing_get(self):
+        out = {}
+        for k, name in enumerate(K_NAMES):
+            ms, la, sy = C.c_double(), C.c_int64(), C.c_int64()
+            self.H.idahip_timing_get(self.h, k, C.byref(ms), C.byref(la), C.byref(sy))
+            out[name] = {"ms": ms.value, "launches": la.value, "systems": sy.value}
+        return out
+
+
+COUNTERS = {"nst": 0, "nre": 1, "nje": 2, "nsetups": 3, "nni": 4, "netf": 5, "ncfn": 6, "n_attempts": 7, "nls_nconvfails": 8,
+            "kused": 9, "kk": 10}
+REALS = {"tn": 0, "hused": 1, "hh": 2, "h0u": 3, "tolsf": 4}
+
+
+class Ensemble:
+    """Batched counterpart of the reference's `Ida` object: Ida::new / Ida::solve / getters for every system of a Ctx."""
+
+    def __init__(self, ctx, yy0, yp0):
+        self.ctx = ctx
+        self.E = ctx.E
+        yy0, yp0 = _f64(yy0).reshape(ctx.batch, ctx.n), _f64(yp0).reshape(ctx.batch, ctx.n)
+        h = C.c_void_p()
+        rc = self.E.idaens_create(C.byref(h), ctx.h, _p(yy0), _p(yp0))
+        if rc != 0:
+            raise IdaHipError("idaens_create failed (%d): %s" % (rc, ctx.H.idahip_last_error(ctx.h).decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.E.idaens_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_max_num_steps(self, mxstep):
+        self.E.idaens_set_max_num_steps(self.h, int(mxstep))
+
+    def solve(self, tout, itask=0, max_rounds=0):
+        tret = np.zeros(self.ctx.batch)
+        status = np.zeros(self.ctx.batch, dtype=np.int32)
+        rc = self.E.idaens_solve(self.h, float(tout), int(itask), _p(tret), _p(status, i32p), int(max_rounds))
+        if rc < 0:
+            raise IdaHipError("idaens_solve failed (%d): %s" % (rc, self.E.idaens_last_error(self.h).decode()))
+        return status, tret
+
+    def counter(self, name):
+        out = np.zeros(self.ctx.batch, dtype=np.int64)
+        assert self.E.idaens_get_counter(self.h, COUNTERS[name], _p(out, i64p)) == 0
+        return out
+
+    def counters(self):
+        return {k: self.counter(k) for k in COUNTERS}
+
+    def real(self, name):
+        out = np.zeros(self.ctx.batch)
+        assert self.E.idaens_get_real(self.h, REALS[name], _p(out)) == 0
+        return out
+
+    def yy(self):
+        out = np.empty((self.ctx.batch, self.ctx.n))
+        assert self.E.idaens_get_yy(self.h, _p(out)) == 0
+        return out
+
+    def yp(self):
+        out = np.empty((self.ctx.batch, self.ctx.n))
+        assert self.E.idaens_get_yp(self.h, _p(out)) == 0
+        return out
+
+    def total_newton_iters(self):
+        return int(self.E.idaens_total_newton_iters(self.h))
+
+    def total_rounds(self):
+        return int(self.E.idaens_total_rounds(self.h))
+
+    def trace_system(self, sys):
+        self.E.idaens_trace_system(self.h, int(sys))
+
+    def trace(self):
+        k = self.E.idaens_trace_len(self.h)
+        out = np.zeros((k, 3))
+        if k:
+            self.E.idaens_trace_get(self.h, _p(out))
+        return out

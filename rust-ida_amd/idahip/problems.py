@@ -1,0 +1,110 @@
+"""Synthetic problem generators for the configurations of BASELINE.json / SURVEY.md 8(d).
+
+Pure input generation (numpy): matrices, parameters, consistent initial conditions, tolerances, output grids. The
+reference ships none of these except Roberts (examples/roberts.rs:64-70) and the Lorenz parameters
+(tests/lorenz63.rs:17-25); everything else is this build's choice, fixed here so CPU oracle and GPU path integrate
+identical inputs.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def roberts():
+    """Config 1 -- examples/roberts.rs:64-70, 95-136."""
+    return {
+        "kind": "roberts", "n": 3, "yy0": np.array([[1.0, 0.0, 0.0]]), "yp0": np.array([[-0.04, 0.04, 0.0]]),
+        "rtol": 1.0e-4, "atol": np.array([1.0e-8, 1.0e-6, 1.0e-6]), "touts": 0.4 * 10.0 ** np.arange(12),
+    }
+
+
+def lorenz63(batch=1024, seed=63):
+    """Config 2 -- Lorenz63 as an index-0 DAE. p, r, b from tests/lorenz63.rs:17-25; ICs/tolerances/horizon are ours:
+    y(0) = [1,1,1] + 1e-3*u_b, u_b ~ U(-1,1)^3 (PCG64 seed 63), y'(0) = f(y(0)), rtol 1e-6, atol 1e-9, t = 0.1..5.0."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = rng.uniform(-1.0, 1.0, size=(batch, 3))
+    y0 = 1.0 + 1.0e-3 * u
+    p, r, b = 10.0, 28.0, 8.0 / 3.0
+    yp0 = np.stack([p * (y0[:, 1] - y0[:, 0]), y0[:, 0] * (r - y0[:, 2]) - y0[:, 1], y0[:, 0] * y0[:, 1] - b * y0[:, 2]], axis=1)
+    params = np.tile(np.array([p, r, b]), (batch, 1))
+    return {"kind": "lorenz63", "n": 3, "yy0": y0, "yp0": yp0, "params": params, "rtol": 1.0e-6, "atol": np.array([1.0e-9]),
+            "touts": 0.1 * np.arange(1, 51)}
+
+
+def _linear_system(n, b):
+    """One system of config 3: returns (A_colmajor, B_colmajor, c, y0, yp0)."""
+    rng = np.random.Generator(np.random.PCG64(n * 1000003 + b))
+    R = rng.uniform(-1.0, 1.0, size=(n, n))
+    G = rng.standard_normal(size=(n, n))
+    s = rng.uniform(0.0, 1.0)
+    c = rng.uniform(-1.0, 1.0, size=n)
+    nd = (3 * n) // 4  # differential unknowns first, algebraic last
+    R[nd:, :] = 0.0
+    R[:, nd:] = 0.0
+    A = 0.01 * R
+    A[np.arange(nd), np.arange(nd)] += 1.0
+    Bm = -((0.5 / np.sqrt(n)) * G)
+    Bm[np.arange(n), np.arange(n)] -= (1.0 + s)
+    # consistent initial conditions (the reference has no IDACalcIC: src/lib.rs:328-335)
+    y0 = np.zeros(n)
+    yp0 = np.zeros(n)
+    if nd < n:
+        y0[nd:] = np.linalg.solve(Bm[nd:, nd:], c[nd:])
+    if nd > 0:
+        yp0[:nd] = np.linalg.solve(A[:nd, :nd], c[:nd] - Bm[:nd, nd:] @ y0[nd:])
+    return np.ascontiguousarray(A.T), np.ascontiguousarray(Bm.T), c, y0, yp0
+
+
+def linear_dense(n=512, batch=4096, first=0, threads=8):
+    """Config 3/5 -- synthetic random linear dense index-1 DAE F = A y' + B y - c, systems [first, first+batch).
+    Matrices are returned column-major per system (array[s, j, i] = M_s(i, j))."""
+    A = np.empty((batch, n, n))
+    Bm = np.empty((batch, n, n))
+    c = np.empty((batch, n))
+    y0 = np.empty((batch, n))
+    yp0 = np.empty((batch, n))
+
+    def work(s):
+        A[s], Bm[s], c[s], y0[s], yp0[s] = _linear_system(n, first + s)
+
+    if threads > 1 and batch > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(work, range(batch)))
+    else:
+        for s in range(batch):
+            work(s)
+    return {"kind": "linear_dense", "n": n, "A": A, "B": Bm, "c": c, "yy0": y0, "yp0": yp0, "rtol": 1.0e-6,
+            "atol": np.array([1.0e-8]), "touts": 0.1 * np.arange(1, 11)}
+
+
+def heat1d(n=4096, batch=256):
+    """Config 4 -- 1-D heat equation u_t = kappa u_xx, method of lines on n nodes, Dirichlet ends as algebraic equations;
+    kappa_b = 1 + b/256; y_i(0) = sin(pi x_i) with exact zeros at both ends; y'(0) = the interior right-hand side."""
+    dx = 1.0 / (n - 1)
+    x = np.arange(n) * dx
+    y = np.sin(np.pi * x)
+    y[0] = 0.0
+    y[-1] = 0.0
+    kappa = 1.0 + np.arange(batch) / 256.0
+    coef = kappa / (dx * dx)
+    y0 = np.tile(y, (batch, 1))
+    yp0 = np.zeros((batch, n))
+    yp0[:, 1:-1] = coef[:, None] * ((y[None, :-2] - 2.0 * y[None, 1:-1]) + y[None, 2:])
+    return {"kind": "heat1d", "n": n, "yy0": y0, "yp0": yp0, "params": coef.reshape(batch, 1), "rtol": 1.0e-5,
+            "atol": np.array([1.0e-8]), "touts": 0.01 * np.arange(1, 11)}
+
+
+def make_ctx(prob, device=0, stream=None):
+    """Create a device context for a generated problem and load its data (import kept local: this module is also
+    used by CPU-only tests)."""
+    from . import Ctx
+    batch = prob["yy0"].shape[0]
+    ctx = Ctx(prob["kind"], prob["n"], batch, device=device, stream=stream)
+    ctx.set_tolerances(prob["rtol"], prob["atol"])
+    if prob["kind"] == "linear_dense":
+        step = max(1, (1 << 28) // (8 * prob["n"] * prob["n"]))  # <= 256 MiB per matrix upload
+        for f in range(0, batch, step):
+            ctx.set_linear_dense(prob["A"][f:f + step], prob["B"][f:f + step], prob["c"][f:f + step], first=f)
+    elif "params" in prob:
+        ctx.set_problem_params(prob["params"])
+    return ctx
