@@ -126,12 +126,17 @@ def test_one_step_mode_and_interpolation_past_tout():
         assert np.array_equal(o[s].getv("yy"), ens.yy()[s])
     # Normal mode to t=0.5, then a tout already passed -> pure interpolation (stop_test1)
     ens.solve(0.5)
-    st, tret = ens.solve(0.45)
+    t2 = float(np.min(ens.real("tn") - 0.25 * ens.real("hused")))  # inside every system's last step
+    st, tret = ens.solve(t2)
+    yy, yp = ens.yy(), ens.yp()
     for s in range(2):
         o[s].solve(0.5)
-        so, to = o[s].solve(0.45)
-        assert so == st[s] == 0 and to == tret[s] == 0.45
-        assert np.array_equal(o[s].getv("yy"), ens.yy()[s]) and np.array_equal(o[s].getv("yp"), ens.yp()[s])
+        so, to = o[s].solve(t2)
+        assert so == st[s] == 0 and to == tret[s] == t2
+        assert np.array_equal(o[s].getv("yy"), yy[s]) and np.array_equal(o[s].getv("yp"), yp[s])
+    # a tout before the last step is rejected by both (IdaError::BadTimeValue)
+    st, _ = ens.solve(0.01)
+    assert (st == -26).all() and all(o[s].solve(0.01)[0] == -26 for s in range(2))
 
 
 def test_round_limited_solve_resumes_identically():
