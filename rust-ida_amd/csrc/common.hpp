@@ -174,6 +174,16 @@ struct KTimer {
     }
 };
 
+// Load through the constant address space: for wave-uniform addresses of memory that no thread of the running kernel
+// writes, hipcc then emits scalar loads (s_load_dword*) and the value lives in SGPRs -- usable directly as a VALU
+// operand, with no LDS or vector-memory traffic. (A plain load from a struct-member pointer is a per-lane
+// global_load even when the address is uniform.)
+template <class T>
+__device__ __forceinline__ T ldc(const T* p) {
+    typedef const T __attribute__((address_space(4))) * cptr;
+    return *reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-uniform */) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

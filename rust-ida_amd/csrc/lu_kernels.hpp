@@ -22,7 +22,10 @@
 //   * a final pass scatters rows to their pivoted positions (the reference layout the solve kernels stream).
 // Blocking changes neither the per-element operation order nor any operand, only when each update is applied.
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
+#include "lu_left.hpp"
 
 namespace idahip {
 
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
     __shared__ int s_p[2][16];
     __shared__ double s_prow[2][NB + 1];  // [..][NB] = 1/pivot
     __shared__ int s_cnt[16];
+    __shared__ unsigned s_zm[2];
 
     const bool valid = t < m;
     const int r = valid ? live[t] : 0;
@@ -123,10 +127,15 @@ __global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
             }
             const bool owner = alive && (mypos == bp);
             if (owner) {
+                unsigned zm = 0u;
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    if (j >= k) s_prow[k & 1][j] = a[j];
+                    if (j >= k) {
+                        s_prow[k & 1][j] = a[j];
+                        if (j > k && a[j] == 0.0) zm |= 1u << j;
+                    }
                 s_prow[k & 1][NB] = 1.0 / a[k];  // mult = a(k,k).recip()  (dense.rs:134)
+                s_zm[k & 1] = zm;                // columns whose update is skipped (a_kj == 0, dense.rs:148)
             }
             __syncthreads();
             const double pk = s_prow[k & 1][k];
@@ -145,12 +154,15 @@ __global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
                     const double mult = s_prow[k & 1][NB];
                     a[k] *= mult;
                     const double aik = a[k];
+                    const unsigned zm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_zm[k & 1]);
+                    if (zm == 0u) {
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        if (j > k && j < wd) {
-                            const double akj = s_prow[k & 1][j];
-                            if (akj != 0.0) a[j] -= akj * aik;  // dense.rs:148-152
-                        }
+                        for (int j = 0; j < NB; ++j)
+                            if (j > k && j < wd) a[j] -= s_prow[k & 1][j] * aik;  // dense.rs:151
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            if (j > k && j < wd && !((zm >> j) & 1u)) a[j] -= s_prow[k & 1][j] * aik;
                     }
                 }
             }
@@ -198,21 +210,31 @@ __global__ __launch_bounds__(64) void lu_trsm_kernel(LuWs w, int k0) {
 
     double u[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) u[k] = valid ? A[(long)jc * n + prow[k]] : 0.0;
+    for (int k = 0; k < NB; ++k) u[k] = valid ? A[(long)jc * n + ldc(prow + k)] : 0.0;
 
+    // Right-looking order over the source row kk: u[kk] is final once rows 0..kk-1 have been applied, and every target
+    // u[k], k > kk, still receives its updates in ascending kk. The a_kj == 0 skip (dense.rs:148) is per column
+    // (= per lane) here; one ballot per source row selects the unpredicated body when no lane holds a zero.
     bool anyzero = !valid;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
+    for (int kk = 0; kk < NB; ++kk) {
+        const double ukk = u[kk];
+        const bool z = (ukk == 0.0);
+        anyzero = anyzero || z;
+        if (valid) A[(long)jc * n + ldc(prow + kk)] = ukk;
+        if (inpad) U[(long)kk * w.npad16 + jc] = ukk;
+        if (__ballot(z) == 0ull) {
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) {
-            if (kk < k) {
-                const double l = l11[k * NB + kk];
-                if (u[kk] != 0.0) u[k] -= u[kk] * l;  // a(i,j) -= a_kj * a_ik, ascending kk
-            }
+            for (int k = 0; k < NB; ++k)
+                if (k > kk) u[k] -= ukk * ldc(l11 + k * NB + kk);  // a(i,j) -= a_kj * a_ik
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (k > kk) {
+                    const double t = u[k] - ukk * ldc(l11 + k * NB + kk);
+                    u[k] = z ? u[k] : t;
+                }
         }
-        anyzero = anyzero || (u[k] == 0.0);
-        if (valid) A[(long)jc * n + prow[k]] = u[k];
-        if (inpad) U[(long)k * w.npad16 + jc] = u[k];
     }
     const unsigned long long bal = __ballot(anyzero);
     if ((lane & 15) == 0 && inpad) uz[jc >> 4] = ((bal >> (lane & 48)) & 0xffffull) != 0ull;
@@ -248,18 +270,18 @@ __global__ __launch_bounds__(256) void lu_update_kernel(LuWs w, int k0, int cspl
 #pragma unroll
         for (int j = 0; j < 16; ++j) c[j] = (c0 + j < n) ? A[(long)(c0 + j) * n + r] : 0.0;
         const double* __restrict__ U = Ub + c0;
-        if (uz[c0 >> 4] == 0) {
+        if (ldc(uz + (c0 >> 4)) == 0) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) c[j] -= U[(long)k * w.npad16 + j] * l[k];
+                for (int j = 0; j < 16; ++j) c[j] -= ldc(U + (long)k * w.npad16 + j) * l[k];
             }
         } else {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const double ukj = U[(long)k * w.npad16 + j];
+                    const double ukj = ldc(U + (long)k * w.npad16 + j);
                     if (ukj != 0.0) c[j] -= ukj * l[k];
                 }
             }
@@ -348,6 +370,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         return 0;
     }
     if (n > LU_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_MAX_N, n);
+    static const bool use_right = getenv("IDAHIP_LU_RIGHT") != nullptr;  // A/B switch: multi-kernel right-looking pipeline
+    if (!use_right) return lu_left_launch(c, work, wstride, out, ostride, piv, pstride, perm, d_idx, nsys);
     constexpr int NB = LU_NB;
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n; w.npad16 = c->npad16;

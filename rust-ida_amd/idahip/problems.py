@@ -5,8 +5,6 @@ reference ships none of these except Roberts (examples/roberts.rs:64-70) and the
 (tests/lorenz63.rs:17-25); everything else is this build's choice, fixed here so CPU oracle and GPU path integrate
 identical inputs.
 """
-from concurrent.futures import ThreadPoolExecutor
-
 import numpy as np
 
 
@@ -55,24 +53,59 @@ def _linear_system(n, b):
     return np.ascontiguousarray(A.T), np.ascontiguousarray(Bm.T), c, y0, yp0
 
 
-def linear_dense(n=512, batch=4096, first=0, threads=8):
-    """Config 3/5 -- synthetic random linear dense index-1 DAE F = A y' + B y - c, systems [first, first+batch).
-    Matrices are returned column-major per system (array[s, j, i] = M_s(i, j))."""
-    A = np.empty((batch, n, n))
-    Bm = np.empty((batch, n, n))
-    c = np.empty((batch, n))
-    y0 = np.empty((batch, n))
-    yp0 = np.empty((batch, n))
+_SHARED = {}
 
-    def work(s):
-        A[s], Bm[s], c[s], y0[s], yp0[s] = _linear_system(n, first + s)
 
-    if threads > 1 and batch > 1:
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            list(ex.map(work, range(batch)))
+def _shared_array(shape):
+    """float64 array in anonymous shared memory (inherited by forked workers, freed with the last reference)."""
+    import mmap
+    nbytes = int(np.prod(shape)) * 8
+    mm = mmap.mmap(-1, max(nbytes, 8))
+    return np.frombuffer(mm, dtype=np.float64, count=int(np.prod(shape))).reshape(shape)
+
+
+def _fill_range(args):
+    n, first, lo, hi, limit_blas = args
+    A, Bm, c, y0, yp0 = _SHARED["arrays"]
+
+    def fill():
+        for s in range(lo, hi):
+            A[s], Bm[s], c[s], y0[s], yp0[s] = _linear_system(n, first + s)
+
+    if limit_blas:  # one BLAS thread per worker process
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1):
+                fill()
+        except ImportError:
+            fill()
     else:
-        for s in range(batch):
-            work(s)
+        fill()
+    return hi - lo
+
+
+def linear_dense(n=512, batch=4096, first=0, procs=1, threads=None):
+    """Config 3/5 -- synthetic random linear dense index-1 DAE F = A y' + B y - c, systems [first, first+batch).
+    Matrices are returned column-major per system (array[s, j, i] = M_s(i, j)). `procs` > 1 generates with forked
+    worker processes into shared memory (call before the process touches the GPU)."""
+    if threads is not None:  # backwards-compatible alias
+        procs = threads
+    shapes = [(batch, n, n), (batch, n, n), (batch, n), (batch, n), (batch, n)]
+    if procs > 1 and batch >= 2 * procs:
+        import multiprocessing as mp
+        arrays = [_shared_array(sh) for sh in shapes]
+        _SHARED["arrays"] = arrays
+        step = max(1, batch // (procs * 4))
+        jobs = [(n, first, lo, min(batch, lo + step), True) for lo in range(0, batch, step)]
+        with mp.get_context("fork").Pool(procs) as pool:
+            assert sum(pool.map(_fill_range, jobs)) == batch
+        _SHARED.pop("arrays")
+    else:
+        arrays = [np.empty(sh) for sh in shapes]
+        _SHARED["arrays"] = arrays
+        _fill_range((n, first, 0, batch, False))
+        _SHARED.pop("arrays")
+    A, Bm, c, y0, yp0 = arrays
     return {"kind": "linear_dense", "n": n, "A": A, "B": Bm, "c": c, "yy0": y0, "yp0": yp0, "rtol": 1.0e-6,
             "atol": np.array([1.0e-8]), "touts": 0.1 * np.arange(1, 11)}
 
