@@ -190,6 +190,43 @@ __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-unifor
     return __hiloint2double(hi, lo);
 }
 
+// ---- wave64 reductions on the DPP crossbar (no LDS round trips): row_shr 1/2/4/8 fold each 16-lane row into its last
+// lane, row_bcast:15 / row_bcast:31 fold the four rows into lane 63; the result is read back with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov_i32(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);  // lanes without a source keep their own value
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    const int lo = dpp_mov_i32<CTRL, ROW_MASK>(__double2loint(x));
+    const int hi = dpp_mov_i32<CTRL, ROW_MASK>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+// max over the wave of a NaN-free double; every lane returns the maximum
+__device__ __forceinline__ double wave_max_f64(double v) {
+    double o;
+    o = dpp_mov_f64<0x111, 0xf>(v); v = o > v ? o : v;  // row_shr:1
+    o = dpp_mov_f64<0x112, 0xf>(v); v = o > v ? o : v;  // row_shr:2
+    o = dpp_mov_f64<0x114, 0xf>(v); v = o > v ? o : v;  // row_shr:4
+    o = dpp_mov_f64<0x118, 0xf>(v); v = o > v ? o : v;  // row_shr:8
+    o = dpp_mov_f64<0x142, 0xa>(v); v = o > v ? o : v;  // row_bcast:15 -> rows 1, 3
+    o = dpp_mov_f64<0x143, 0xc>(v); v = o > v ? o : v;  // row_bcast:31 -> rows 2, 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// min over the wave of an int; every lane returns the minimum
+__device__ __forceinline__ int wave_min_i32(int v) {
+    int o;
+    o = dpp_mov_i32<0x111, 0xf>(v); v = o < v ? o : v;
+    o = dpp_mov_i32<0x112, 0xf>(v); v = o < v ? o : v;
+    o = dpp_mov_i32<0x114, 0xf>(v); v = o < v ? o : v;
+    o = dpp_mov_i32<0x118, 0xf>(v); v = o < v ? o : v;
+    o = dpp_mov_i32<0x142, 0xa>(v); v = o < v ? o : v;
+    o = dpp_mov_i32<0x143, 0xc>(v); v = o < v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     const int lo = __shfl_xor(__double2loint(v), mask);
     const int hi = __shfl_xor(__double2hiint(v), mask);

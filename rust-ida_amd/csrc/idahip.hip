@@ -627,6 +627,15 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
     return ap.finish_async();
 }
 
+#ifdef IDAHIP_STAMPS
+// development only: raw read of the LU workspace that debug builds fill with s_memtime stamps
+int idahip_debug_ubuf(idahip_ctx* c, void* h, size_t bytes) {
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    IDAHIP_HIP(c, hipMemcpy(h, c->lu_ubuf, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ measurement
 int idahip_timing_enable(idahip_ctx* c, int on) {
     if (!c) return -1;

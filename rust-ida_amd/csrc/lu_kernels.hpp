@@ -41,9 +41,10 @@ struct LuWs {
     long long* piv;    // [batch][n] reference pivots (position chosen at step k)
     long pstride;      // elements between consecutive systems in piv
     int* info;         // [batch]   0 | 1-based zero-pivot column
-    double* l11;       // [batch][NB*NB] row k = multipliers of the k-th pivot row
+    double* l11;       // [batch][NB*NB] transposed L11: l11[kk*NB + k] = multiplier of the k-th pivot row for column kk
     double* ubuf;      // [batch][NB][npad16] U12 rows, contiguous along columns
     int* uz;           // [batch][npad16/16] 1 if the 16-column chunk of U12 holds an exact zero (or padding)
+    int dbg;           // timing experiments only (IDAHIP_LU_DBG): skip phases of lu_trail_kernel; results are then wrong
 };
 
 __global__ void lu_init_kernel(LuWs w) {
@@ -56,8 +57,21 @@ __global__ void lu_init_kernel(LuWs w) {
 }
 
 // ------------------------------------------------------------------------------------------------ panel
-template <int NB, int MAXT>
-__global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
+// One workgroup per matrix, one live row per thread, the row's NB panel entries in registers.
+//  * The column loop is a real (rolled) loop: registers rotate by one column per step -- the update of column j is
+//    written into register j-1, a(j-1) <- a(j) - prow(j)*a_ik, at no extra instruction -- so the pivot column is always
+//    register 0 and a step is ~250 instructions (a fully unrolled NB x NB triangle is > 100 KB of code run once).
+//  * ONE LDS-only barrier per column: every wave reduces its own arg-max on the DPP crossbar and its winning lane
+//    publishes (|a|, position, the whole candidate row, 1/pivot, zero mask) speculatively; after the barrier every
+//    thread picks the global winner among the <= 16 wave candidates and reads that wave's row. No serial owner
+//    section, and the barrier does not drain the multiplier stores (raw s_barrier + lgkmcnt only).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NB, int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
+    constexpr int NW = MAXT / 64;
+    constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
+    static_assert(NW <= 16 && NB == 32, "candidate scan assumes <= 16 waves, zero mask assumes NB == 32");
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -70,117 +84,167 @@ __global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
 
     const int m = n - k0;
     const int wd = m < NB ? m : NB;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
-    __shared__ double s_v[2][16];
-    __shared__ int s_p[2][16];
-    __shared__ double s_prow[2][NB + 1];  // [..][NB] = 1/pivot
-    __shared__ int s_cnt[16];
-    __shared__ unsigned s_zm[2];
+    __shared__ __align__(16) double s_row[2][NW][LDR];
+    __shared__ __align__(16) double s_v[2][16];
+    __shared__ __align__(16) int s_p[2][16];
+    __shared__ unsigned s_zm[2][NW];
+    __shared__ int s_r[2][NW];
+    __shared__ int s_cnt[NW];
 
+#ifdef IDAHIP_STAMPS
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_, tn_;
+#define TNOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory")
+#define PH(i) do { TNOW(tn_); acc_[i] += tn_ - tp_; tp_ = tn_; } while (0)
+    TNOW(tp_);
+#else
+#define PH(i) do {} while (0)
+#endif
+    if (t < 32) {  // slots of waves that do not exist in this launch never win
+        (&s_v[0][0])[t] = -2.0;
+        (&s_p[0][0])[t] = 0x7fffffff;
+    }
     const bool valid = t < m;
     const int r = valid ? live[t] : 0;
     int mypos = valid ? pos[r] : 0x7fffffff;
     double a[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) a[j] = (valid && j < wd) ? A[(long)(k0 + j) * n + r] : 0.0;
+    __syncthreads();
 
     bool alive = valid;
     int ownk = -1;
     bool failed = false;
+    PH(0);  // loads
 
+#pragma unroll 1
+    for (int k = 0; k < wd; ++k) {
+        const int kc = k0 + k;
+        const int par = k & 1;
+        // candidate key: (|a|, position); NaN only wins if it sits at position kc (dense.rs:111-117 scan semantics)
+        double v = -1.0;
+        int p = 0x7fffffff;
+        if (alive) {
+            v = fabs(a[0]);
+            p = mypos;
+            if (v != v) v = (mypos == kc) ? __builtin_huge_val() : -1.0;
+        }
+        // every lane forms the reciprocal of its own candidate pivot: the divide overlaps the reduction below instead
+        // of sitting, single-lane, on the critical path of the winner.   mult = a(k,k).recip()  (dense.rs:134)
+        const double myrecip = 1.0 / a[0];
+        const double vm = wave_max_f64(v);
+        const int pm = wave_min_i32(v == vm ? p : 0x7fffffff);
+        PH(1);  // reduce
+        const bool cand = alive && p == pm && v == vm;  // this wave's candidate row (one lane, or none)
+        if (cand) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (k < wd && !failed) {
-            const int kc = k0 + k;
-            // candidate key: (|a|, position); NaN only wins if it sits at position kc (dense.rs:111-117 scan semantics)
-            double v = -1.0;
-            int p = 0x7fffffff;
-            if (alive) {
-                v = fabs(a[k]);
-                p = mypos;
-                if (v != v) v = (mypos == kc) ? __builtin_huge_val() : -1.0;
+            for (int j = 0; j < NB; j += 2) {
+                double2 q;
+                q.x = a[j];
+                q.y = a[j + 1];
+                *reinterpret_cast<double2*>(&s_row[par][wave][j]) = q;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = shfl_xor_f64(v, off);
-                const int op = __shfl_xor(p, off);
-                if (ov > v || (ov == v && op < p)) {
-                    v = ov;
-                    p = op;
-                }
-            }
+            s_row[par][wave][NB] = myrecip;
+            s_r[par][wave] = r;
+        }
+        // zero mask of the candidate row (dense.rs:148): lanes 1..NB-1 re-read one entry each, one ballot
+        {
+            const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
+            const unsigned zm = (unsigned)(__ballot(lane > 0 && lane < NB && e == 0.0) & 0xffffffffull);
             if (lane == 0) {
-                s_v[k & 1][wave] = v;
-                s_p[k & 1][wave] = p;
-            }
-            __syncthreads();
-            double bv = s_v[k & 1][0];
-            int bp = s_p[k & 1][0];
-            for (int q = 1; q < nwaves; ++q) {
-                const double ov = s_v[k & 1][q];
-                const int op = s_p[k & 1][q];
-                if (ov > bv || (ov == bv && op < bp)) {
-                    bv = ov;
-                    bp = op;
-                }
-            }
-            const bool owner = alive && (mypos == bp);
-            if (owner) {
-                unsigned zm = 0u;
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    if (j >= k) {
-                        s_prow[k & 1][j] = a[j];
-                        if (j > k && a[j] == 0.0) zm |= 1u << j;
-                    }
-                s_prow[k & 1][NB] = 1.0 / a[k];  // mult = a(k,k).recip()  (dense.rs:134)
-                s_zm[k & 1] = zm;                // columns whose update is skipped (a_kj == 0, dense.rs:148)
-            }
-            __syncthreads();
-            const double pk = s_prow[k & 1][k];
-            if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
-                if (t == 0) w.info[b] = kc + 1;
-                failed = true;
-            } else {
-                if (t == 0) piv[kc] = (long long)bp;
-                if (owner) {
-                    prow[kc] = r;
-                    ownk = k;
-                    alive = false;
-                    mypos = kc;
-                } else if (alive) {
-                    if (mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
-                    const double mult = s_prow[k & 1][NB];
-                    a[k] *= mult;
-                    const double aik = a[k];
-                    const unsigned zm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_zm[k & 1]);
-                    if (zm == 0u) {
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            if (j > k && j < wd) a[j] -= s_prow[k & 1][j] * aik;  // dense.rs:151
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            if (j > k && j < wd && !((zm >> j) & 1u)) a[j] -= s_prow[k & 1][j] * aik;
-                    }
-                }
+                s_zm[par][wave] = zm;
+                s_v[par][wave] = vm;   // -1 when the wave has no live row
+                s_p[par][wave] = pm;
             }
         }
+        PH(2);  // candidate publish
+        lds_barrier();
+        PH(3);  // barrier wait
+        // global winner among <= 16 wave candidates: lane q < 16 takes candidate q, 4-step DPP fold inside the row
+        double bv;
+        int bp, bw;
+        {
+            const int q = lane & 15;
+            double cv = s_v[par][q];
+            int cp = s_p[par][q];
+            // max |a|
+            double o;
+            double mv = cv;
+            o = dpp_mov_f64<0x111, 0xf>(mv); mv = o > mv ? o : mv;
+            o = dpp_mov_f64<0x112, 0xf>(mv); mv = o > mv ? o : mv;
+            o = dpp_mov_f64<0x114, 0xf>(mv); mv = o > mv ? o : mv;
+            o = dpp_mov_f64<0x118, 0xf>(mv); mv = o > mv ? o : mv;
+            bv = readlane_f64(mv, 15);
+            // lowest position among the candidates attaining it; the wave index rides in the low 4 bits of the key
+            long long key = (cv == bv) ? (((long long)cp << 4) | q) : 0x7fffffffffffffffll;
+            int klo = (int)(key & 0xffffffffll), khi = (int)(key >> 32);
+            // positions are < 2^27, so (pos << 4 | q) fits in 31 bits: compare the low word only
+            int kk_ = (cv == bv) ? ((cp << 4) | q) : 0x7fffffff;
+            (void)klo; (void)khi;
+            int oi;
+            oi = dpp_mov_i32<0x111, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
+            oi = dpp_mov_i32<0x112, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
+            oi = dpp_mov_i32<0x114, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
+            oi = dpp_mov_i32<0x118, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
+            const int kmin = __builtin_amdgcn_readlane(kk_, 15);
+            bp = kmin >> 4;
+            bw = kmin & 15;
+        }
+        PH(4);  // scan
+        const double pk = s_row[par][bw][0];
+        if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
+            if (t == 0) w.info[b] = kc + 1;
+            failed = true;
+            break;
+        }
+        if (t == 0) piv[kc] = (long long)bp;
+        const bool owner = alive && (mypos == bp);
+        if (owner) {
+            prow[kc] = r;
+            ownk = k;
+            alive = false;
+            mypos = kc;
+        }
+        // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
+        if (wave == 0 && lane < NB && k + lane < wd && !(w.dbg & 64))
+            A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
+        PH(5);  // pivot bookkeeping + row store
+        if (!owner && alive && !(w.dbg & 32)) {
+            if (mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
+            const double aik = a[0] * s_row[par][bw][NB];
+            if (!(w.dbg & 64)) A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
+            const unsigned zm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_zm[par][bw]);
+            if (zm == 0u) {
+#pragma unroll
+                for (int jc = 0; jc < NB; jc += 8) {
+                    double u[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
+                        u[j] = q.x;
+                        u[j + 1] = q.y;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (jc + j >= 1) a[jc + j - 1] = a[jc + j] - u[j] * aik;  // dense.rs:151, rotated one column
+                }
+            } else {
+#pragma unroll
+                for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1u) ? a[j] : a[j] - s_row[par][bw][j] * aik;
+            }
+            a[NB - 1] = 0.0;
+        }
+        PH(6);  // update
     }
     if (failed) return;
 
-    // write back the panel, positions, L11 and the compacted live list
-    if (valid) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (j < wd) A[(long)(k0 + j) * n + r] = a[j];
-        pos[r] = mypos;
-        if (ownk >= 0) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                if (j < ownk) l11[ownk * NB + j] = a[j];
-        }
+    // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
+    if (valid) pos[r] = mypos;
+    __syncthreads();  // the multipliers stored above are visible to the whole workgroup
+    if (ownk > 0) {
+        for (int j = 0; j < ownk; ++j) l11[j * NB + ownk] = A[(long)(k0 + j) * n + r];  // [kk][k]: a TRSM step reads a contiguous run
     }
     const unsigned long long bal = __ballot(alive);
     if (lane == 0) s_cnt[wave] = __popcll(bal);
@@ -188,6 +252,13 @@ __global__ __launch_bounds__(MAXT) void lu_panel_kernel(LuWs w, int k0) {
     int base = 0;
     for (int q = 0; q < wave; ++q) base += s_cnt[q];
     if (alive) live[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+#ifdef IDAHIP_STAMPS
+    PH(7);  // epilogue
+    if (lane == 0 && k0 == 0 && blockIdx.x < 8) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(w.ubuf) + ((long)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = acc_[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ trsm (U12)
@@ -226,12 +297,12 @@ __global__ __launch_bounds__(64) void lu_trsm_kernel(LuWs w, int k0) {
         if (__ballot(z) == 0ull) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
-                if (k > kk) u[k] -= ukk * ldc(l11 + k * NB + kk);  // a(i,j) -= a_kj * a_ik
+                if (k > kk) u[k] -= ukk * ldc(l11 + kk * NB + k);  // a(i,j) -= a_kj * a_ik
         } else {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
                 if (k > kk) {
-                    const double t = u[k] - ukk * ldc(l11 + k * NB + kk);
+                    const double t = u[k] - ukk * ldc(l11 + kk * NB + k);
                     u[k] = z ? u[k] : t;
                 }
         }
@@ -291,6 +362,177 @@ __global__ __launch_bounds__(256) void lu_update_kernel(LuWs w, int k0, int cspl
             for (int j = 0; j < 16; ++j)
                 if (c0 + j < n) A[(long)(c0 + j) * n + r] = c[j];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trailing (fused)
+// One workgroup per (matrix, block of 64 trailing columns): gathers the NB pivot rows of the block, solves
+// U12 = L11^-1 A12 in LDS (one wave, one column per lane, L11 through the scalar cache), writes the final U rows back,
+// then sweeps every 64-row tile of live rows with an LDS-tiled, register-blocked rank-NB update:
+//   256 threads = 16 x 16, each owning a 4 x 4 tile (rows tx+16i, columns ty+16j); per k the lane reads 4 multipliers
+//   and 4 U entries from LDS (conflict-free b64 reads) for 16 updates -> VALU-bound, ~100 VGPRs, 3 workgroups per CU.
+// No Ubuf round trip, no per-lane operand broadcast; the matrix is touched in coalesced column segments only
+// (the pivot-row gather/scatter is the one strided access: NB x 64 elements per workgroup).
+template <int NB>
+__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
+    const int b = w.idx[blockIdx.x];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;
+    const int* __restrict__ live = w.live + (long)b * n;
+    const int* __restrict__ prow = w.prow + (long)b * n + k0;
+    const double* __restrict__ l11 = w.l11 + (long)b * NB * NB;
+
+    const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
+    const int cb0 = k0 + NB + blockIdx.y * 64;
+    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    constexpr int LD = 66;  // padded row (doubles): rows stay 16-byte aligned, column reads conflict-free
+    __shared__ __align__(16) double Us[NB][LD];
+    __shared__ __align__(16) double Ls[2][NB][LD];
+    __shared__ unsigned short s_live[LU_MAX_N];  // n <= 1024 < 65536
+    __shared__ int s_anyzero;
+
+    for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+    // 1. gather the pivot rows of this column block (wave-uniform k per pass -> prow[k] is a scalar load)
+#pragma unroll
+    for (int pass = 0; pass < NB / 4; ++pass) {
+        const int k = pass * 4 + wave;
+        const int pr = ldc(prow + k);
+        Us[k][lane] = (lane < ncols && !(w.dbg & 4)) ? A[(long)(cb0 + lane) * n + pr] : 1.0;
+    }
+    if (t == 0) s_anyzero = 0;
+    __syncthreads();
+
+    // 3. rank-NB update of every 64-row tile of live rows, software-pipelined: while tile rt is computed from LDS the
+    //    multipliers and the C tile of tile rt+1 are already in flight; one raw barrier per tile (LDS visibility only --
+    //    a __syncthreads() would also drain the tile stores, which nobody in this launch reads).
+    const int tx = t & 15, ty = t >> 4;
+    const int ntiles = (w.dbg & 2) ? 0 : ((mrem + 63) >> 6);
+    int col[4];
+    bool cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cj = ty + 16 * j;
+        cok[j] = cj < ncols;
+        col[j] = cb0 + (cok[j] ? cj : 0);
+    }
+    constexpr int LPT = NB / 4;  // multipliers per thread per tile
+    double lreg[LPT], creg[4][4];
+    int crow[4];
+    bool rok[4];
+
+    auto load_tile = [&](int rt, double (&lr_)[LPT], double (&cr_)[4][4], int (&crow_)[4], bool (&rok_)[4]) {
+        const int lr = rt * 64 + lane;
+        const int lrow = s_live[lr < mrem ? lr : mrem - 1];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) lr_[i] = A[(long)(k0 + wave * LPT + i) * n + lrow];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ri = rt * 64 + tx + 16 * i;
+            rok_[i] = ri < mrem;
+            crow_[i] = s_live[rok_[i] ? ri : mrem - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cr_[i][j] = A[(long)col[j] * n + crow_[i]];
+    };
+
+    // 2. U12 = L11^-1 A12 by wave 0, one column per lane, right-looking over the source row kk
+    if (wave == 0) {
+        double u[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) u[k] = Us[k][lane];
+        const bool real = lane < ncols;
+        bool anyz = false;
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk) {
+            const double ukk = u[kk];
+            const bool z = real && (ukk == 0.0);
+            anyz = anyz || z;
+            if (w.dbg & 1) continue;
+            if (__ballot(z) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (k > kk) u[k] -= ukk * ldc(l11 + kk * NB + k);  // a(i,j) -= a_kj * a_ik, ascending kk
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (k > kk) {
+                        const double tn = u[k] - ukk * ldc(l11 + kk * NB + k);
+                        u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            Us[k][lane] = u[k];
+            if (real && !(w.dbg & 8)) A[(long)(cb0 + lane) * n + ldc(prow + k)] = u[k];
+        }
+        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
+        load_tile(0, lreg, creg, crow, rok);
+    } else {
+        load_tile(0, lreg, creg, crow, rok);  // waves 1-3: first tile in flight while wave 0 solves for U12
+    }
+    __syncthreads();
+    const bool slow = s_anyzero != 0;
+
+#pragma unroll 1
+    for (int rt = 0; rt < ntiles; ++rt) {
+        const int buf = rt & 1;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) Ls[buf][wave * LPT + i][lane] = lreg[i];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        double c[4][4];
+        int srow[4];
+        bool sok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            srow[i] = crow[i];
+            sok[i] = rok[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
+        }
+        if (rt + 1 < ntiles) load_tile(rt + 1, lreg, creg, crow, rok);  // in flight behind the arithmetic below
+        if (w.dbg & 16) {
+        } else if (!slow) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Ls[buf][k][tx + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[k][ty + 16 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < NB; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Ls[buf][k][tx + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[k][ty + 16 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double tn = c[i][j] - uv[j] * lv[i];
+                        c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cok[j] && sok[i]) A[(long)col[j] * n + srow[i]] = c[i][j];
     }
 }
 
@@ -370,31 +612,37 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         return 0;
     }
     if (n > LU_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_MAX_N, n);
-    static const bool use_right = getenv("IDAHIP_LU_RIGHT") != nullptr;  // A/B switch: multi-kernel right-looking pipeline
-    if (!use_right) return lu_left_launch(c, work, wstride, out, ostride, piv, pstride, perm, d_idx, nsys);
+    static const bool use_left = getenv("IDAHIP_LU_LEFT") != nullptr;    // A/B: one-launch left-looking kernel (lu_left.hpp)
+    static const bool use_split = getenv("IDAHIP_LU_SPLIT") != nullptr;  // A/B: separate trsm + scalar-operand update kernels
+    if (use_left) return lu_left_launch(c, work, wstride, out, ostride, piv, pstride, perm, d_idx, nsys);
     constexpr int NB = LU_NB;
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n; w.npad16 = c->npad16;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info;
     w.l11 = c->lu_l11; w.ubuf = c->lu_ubuf; w.uz = c->lu_uz;
+    static const int dbg = getenv("IDAHIP_LU_DBG") ? atoi(getenv("IDAHIP_LU_DBG")) : 0;
+    w.dbg = dbg;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int m = n - k0;
         const int threads = ((m + 63) / 64) * 64;
         if (threads <= 512)
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 512>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+            hipLaunchKernelGGL((lu_panel_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
         else
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 1024>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+            hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
         const int ntrail = n - k0 - NB;
         if (ntrail > 0) {
-            hipLaunchKernelGGL(lu_trsm_kernel<NB>, dim3(nsys, (c->npad16 - (k0 + NB) + 63) / 64), dim3(64), 0, c->stream, w, k0);
-            const int rowgroups = (ntrail + 255) / 256;
-            const int nchunks = (ntrail + 15) / 16;
-            int csplit = 1;
-            // aim for a few thousand workgroups per launch so 256 CUs stay busy across the tail
-            while ((long)nsys * rowgroups * csplit < 4096 && csplit < nchunks) csplit *= 2;
-            if (csplit > nchunks) csplit = nchunks;
-            hipLaunchKernelGGL(lu_update_kernel<NB>, dim3(nsys, rowgroups, csplit), dim3(256), 0, c->stream, w, k0, csplit);
+            if (use_split) {
+                hipLaunchKernelGGL(lu_trsm_kernel<NB>, dim3(nsys, (c->npad16 - (k0 + NB) + 63) / 64), dim3(64), 0, c->stream, w, k0);
+                const int rowgroups = (ntrail + 255) / 256;
+                const int nchunks = (ntrail + 15) / 16;
+                int csplit = 1;
+                while ((long)nsys * rowgroups * csplit < 4096 && csplit < nchunks) csplit *= 2;
+                if (csplit > nchunks) csplit = nchunks;
+                hipLaunchKernelGGL(lu_update_kernel<NB>, dim3(nsys, rowgroups, csplit), dim3(256), 0, c->stream, w, k0, csplit);
+            } else {
+                hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys, (ntrail + 63) / 64), dim3(256), 0, c->stream, w, k0);
+            }
         }
     }
     const int cpb = 32;

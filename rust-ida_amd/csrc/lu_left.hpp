@@ -204,14 +204,10 @@ __global__ __launch_bounds__(T) void lu_left_kernel(LuLeftArgs w) {
                         }
                     }
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ov = shfl_xor_f64(v, off);
-                    const int op = __shfl_xor(p, off);
-                    if (ov > v || (ov == v && op < p)) {
-                        v = ov;
-                        p = op;
-                    }
+                {   // wave arg-max on the DPP crossbar: max |a|, then the lowest position among the lanes that attain it
+                    const double vm = wave_max_f64(v);
+                    p = wave_min_i32(v == vm ? p : 0x7fffffff);
+                    v = vm;
                 }
                 if (lane == 0) {
                     s_v[k & 1][wave] = v;

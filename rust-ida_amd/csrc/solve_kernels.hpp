@@ -33,7 +33,7 @@ __device__ __forceinline__ double seq_sum_lds(const double* sq, int n) {
 // Workgroup-cooperative getrs on the right-hand side held in LDS (bs[0..n)). blockDim.x == 256.
 // VEC = 2 requires n even (16-byte aligned column segments).
 template <int VEC>
-__device__ void wg_getrs(const double* __restrict__ LU, int n, double* bs) {
+__device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, double* bs) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);

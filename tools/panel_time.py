@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Development tool: device time of the LU with phases disabled (IDAHIP_LU_DBG), through the copy-free nls_lsetup path."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rust-ida_amd"))
+import numpy as np
+import idahip
+from idahip import problems
+n, B = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+p = problems.linear_dense(n=n, batch=B, procs=16)
+ctx = problems.make_ctx(p)
+ctx.upload(idahip.F_YY, p["yy0"]); ctx.upload(idahip.F_YP, p["yp0"])
+ctx.timing(True)
+for r in range(3):
+    ctx.timing_reset()
+    rc, info = ctx.nls_lsetup(0.0, 100.0)
+    t = ctx.timing_get()
+    print("rep %d: jac %.3f ms  lu %.3f ms  (%.2f us/matrix) info_any=%d" % (r, t["jac"]["ms"], t["lu"]["ms"], t["lu"]["ms"] * 1e3 / B, int(info.any())))
