@@ -116,7 +116,9 @@ def main():
     cores = os.cpu_count() or 1
     procs = int(os.environ.get("IDAHIP_GEN_PROCS", max(1, min(16, cores // max(1, world)))))  # 1 = no fork (use under rocprofv3)
     t0 = time.time()
-    prob = problems.linear_dense(n=args.n, batch=args.batch, first=rank * args.batch, procs=procs)
+    from idahip import sharding
+    first, count = sharding.shard_range(rank, world, args.batch)
+    prob = problems.linear_dense(n=args.n, batch=count, first=first, procs=procs)
     t_gen = time.time() - t0
 
     cpu = None
@@ -157,15 +159,7 @@ def main():
     barrier()
     tim = run.ctx.timing_get()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_max = float(t.item())
-        it = torch.tensor([iters], dtype=torch.int64, device="cuda")
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        iters_all = int(it.item())
-    else:
-        elapsed_max, iters_all = elapsed, iters
+    elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cuda")
 
     if rank == 0:
         ab = algorithmic_bytes(args.n)
