@@ -127,6 +127,11 @@ int idahip_complete_step(idahip_ctx* ctx, const int32_t* hKused, const double* h
 int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCvals, const double* hDvals,
                         const int32_t* hIdx, int nsys);
 
+/* LU implementation choice (both bit-identical to dense_get_rf): 0 = column-major work matrix, 32-column panels and a
+ * fused trailing kernel (default, fastest at N = 512 in round 1); 1 = row-major work matrix, 16-column sub-panels, rank-64
+ * trailing update (fewer HBM bytes, the one to grow). */
+int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
+
 /* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the
  * ctx stream, and launch counters per kernel class ---- */
 typedef enum {

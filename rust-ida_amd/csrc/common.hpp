@@ -56,7 +56,9 @@ struct idahip_ctx {
     int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr;
-    double *lu_l11 = nullptr, *lu_ubuf = nullptr;
+    double* lu_l11 = nullptr;
+    int lu_variant = 0;  // 0: column-major work matrix, 32-column panels + fused trailing kernel (lu_kernels.hpp)
+                         // 1: row-major work matrix, 16-column sub-panels, rank-64 trailing update (lu_rm.hpp)
 
     // problem data
     double* params = nullptr;  // [batch][nparam]

@@ -1,6 +1,7 @@
 // libidahip.so -- implementation of include/ida_hip.h (single translation unit; gfx950; -ffp-contract=off).
 #include "common.hpp"
 #include "lu_kernels.hpp"
+#include "lu_rm.hpp"
 #include "problem_kernels.hpp"
 #include "solve_kernels.hpp"
 #include "vector_kernels.hpp"
@@ -89,9 +90,8 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
-        rc |= dalloc(c, &c->lu_uz, (size_t)batch * (c->npad16 / 16));
-        rc |= dalloc(c, &c->lu_l11, (size_t)batch * LU_NB * LU_NB);
-        rc |= dalloc(c, &c->lu_ubuf, (size_t)batch * LU_NB * c->npad16);
+        rc |= dalloc(c, &c->lu_uz, (size_t)batch * (c->npad16 / 16 + 2));
+        rc |= dalloc(c, &c->lu_l11, (size_t)batch * (RM_SB + 1) * RM_SB);  // padded: the rolled TRSM reads past a row's end
     }
     if (kind == IDAHIP_LINEAR_DENSE) {
         rc |= dalloc(c, &c->A, bnn); rc |= dalloc(c, &c->B, bnn); rc |= dalloc(c, &c->C, bn);
@@ -105,6 +105,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
         else if (hipEventCreateWithFlags(&c->slots[i].done, hipEventDisableTiming) != hipSuccess) rc = -100;
     }
     if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) rc = -100;
+
     if (rc) {
         idahip_destroy(c);
         return -100;
@@ -124,7 +125,7 @@ int idahip_destroy(idahip_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->lu_ubuf, c->params, c->A, c->B, c->C, c->d_atol_v};
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < NSLOT; ++i) {
@@ -253,6 +254,13 @@ int idahip_ls_setup(idahip_ctx* c, double* dA, int64_t* dPiv, int32_t* hInfo, co
         KTimer kt(c, IDAHIP_K_LU, nsys);
         if (n <= TINY_N) {
             rc = lu_factor_batched(c, dA, nn, dA, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
+        } else if ((c->lu_variant == 1) && n <= LU_MAX_N) {
+            // transpose into the row-major ctx work matrix, factor there, write the factors back column-major into dA
+            RmWs w;
+            w.W = c->jw; w.wstride = nn; w.idx = d_idx; w.n = n;
+            const int nb64 = (n + 63) / 64;
+            hipLaunchKernelGGL(rm_transpose_in_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, w, (const double*)dA, nn);
+            rc = rm_factor_batched(c, c->jw, nn, dA, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
         } else {
             // factor in place in dA (physical row order), scatter rows into the ctx work matrix, copy back
             rc = lu_factor_batched(c, dA, nn, c->jw, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
@@ -385,6 +393,7 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
     const double* d_cj = ap.in(hCj, nsys);
     if ((rc = ap.upload())) return rc;
     double* work = (n <= TINY_N) ? c->lu : c->jw;
+    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);  // Jacobian written row-major for the factorisation
     {
         KTimer kt(c, IDAHIP_K_JAC, nsys);
         switch (c->kind) {
@@ -397,16 +406,25 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
                                    (const double*)c->params, 3, d_idx, d_cj, nsys);
                 break;
             case IDAHIP_LINEAR_DENSE: {
-                int chunks = 1;
-                while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
-                hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A, (const double*)c->B, nn,
-                                   d_idx, d_cj, chunks);
+                if (rm) {
+                    const int nb64 = (n + 63) / 64;
+                    hipLaunchKernelGGL(linear_jac_rm_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, work, (const double*)c->A,
+                                       (const double*)c->B, n, d_idx, d_cj);
+                } else {
+                    int chunks = 1;
+                    while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
+                    hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A,
+                                       (const double*)c->B, nn, d_idx, d_cj, chunks);
+                }
                 break;
             }
             case IDAHIP_HEAT1D: {
                 int chunks = 1;
                 while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
-                hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+                if (rm)
+                    hipLaunchKernelGGL(heat_jac_rm_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+                else
+                    hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
                 break;
             }
         }
@@ -414,7 +432,8 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
     }
     {
         KTimer kt(c, IDAHIP_K_LU, nsys);
-        rc = lu_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys);
+        rc = rm ? rm_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys)
+                : lu_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys);
         if (rc) return rc;
         if ((rc = post_launch(c, "lu"))) return rc;
     }
@@ -627,14 +646,11 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
     return ap.finish_async();
 }
 
-#ifdef IDAHIP_STAMPS
-// development only: raw read of the LU workspace that debug builds fill with s_memtime stamps
-int idahip_debug_ubuf(idahip_ctx* c, void* h, size_t bytes) {
-    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
-    IDAHIP_HIP(c, hipMemcpy(h, c->lu_ubuf, bytes, hipMemcpyDeviceToHost));
+int idahip_set_lu_variant(idahip_ctx* c, int variant) {
+    if (!c || (variant != 0 && variant != 1)) return -1;
+    c->lu_variant = variant;
     return 0;
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------ measurement
 int idahip_timing_enable(idahip_ctx* c, int on) {

@@ -16,16 +16,12 @@
 //     matrices (lock-step batch, hundreds to thousands of workgroups per launch):
 //       lu_panel  : one workgroup per matrix, one live row per thread, the row's NB panel entries in registers;
 //                   wave-shuffle + LDS arg-max, pivot row broadcast through LDS.
-//       lu_trsm   : U12 = L11^-1 A12, one lane per trailing column, L11 through the scalar cache.
-//       lu_update : A22 -= L21 U12, one live row per lane, the row's NB multipliers in registers, 16-column register
-//                   tiles, U12 streamed through SGPRs (scalar loads) -- no LDS traffic, no barriers.
+//       lu_trail  : per (matrix, 64 columns): pivot-row gather, U12 = L11^-1 A12 in LDS (L11 through the scalar
+//                   cache), then A22 -= L21 U12 on 64x64 tiles, 4x4 register tile per thread, operands from LDS.
 //   * a final pass scatters rows to their pivoted positions (the reference layout the solve kernels stream).
 // Blocking changes neither the per-element operation order nor any operand, only when each update is applied.
 #pragma once
-#include <cstdlib>
-
 #include "common.hpp"
-#include "lu_left.hpp"
 
 namespace idahip {
 
@@ -34,7 +30,6 @@ struct LuWs {
     long mstride;      // elements between consecutive systems
     const int* idx;    // [nsys] system ids (device)
     int n;
-    int npad16;
     int* pos;          // [batch][n] physical row -> current reference position
     int* live;         // [batch][n] sorted physical indices of not-yet-pivoted rows
     int* prow;         // [batch][n] pivot step -> physical row
@@ -42,9 +37,6 @@ struct LuWs {
     long pstride;      // elements between consecutive systems in piv
     int* info;         // [batch]   0 | 1-based zero-pivot column
     double* l11;       // [batch][NB*NB] transposed L11: l11[kk*NB + k] = multiplier of the k-th pivot row for column kk
-    double* ubuf;      // [batch][NB][npad16] U12 rows, contiguous along columns
-    int* uz;           // [batch][npad16/16] 1 if the 16-column chunk of U12 holds an exact zero (or padding)
-    int dbg;           // timing experiments only (IDAHIP_LU_DBG): skip phases of lu_trail_kernel; results are then wrong
 };
 
 __global__ void lu_init_kernel(LuWs w) {
@@ -94,14 +86,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     __shared__ int s_r[2][NW];
     __shared__ int s_cnt[NW];
 
-#ifdef IDAHIP_STAMPS
-    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_, tn_;
-#define TNOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory")
-#define PH(i) do { TNOW(tn_); acc_[i] += tn_ - tp_; tp_ = tn_; } while (0)
-    TNOW(tp_);
-#else
-#define PH(i) do {} while (0)
-#endif
     if (t < 32) {  // slots of waves that do not exist in this launch never win
         (&s_v[0][0])[t] = -2.0;
         (&s_p[0][0])[t] = 0x7fffffff;
@@ -117,7 +101,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     bool alive = valid;
     int ownk = -1;
     bool failed = false;
-    PH(0);  // loads
 
 #pragma unroll 1
     for (int k = 0; k < wd; ++k) {
@@ -136,7 +119,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
         const double myrecip = 1.0 / a[0];
         const double vm = wave_max_f64(v);
         const int pm = wave_min_i32(v == vm ? p : 0x7fffffff);
-        PH(1);  // reduce
         const bool cand = alive && p == pm && v == vm;  // this wave's candidate row (one lane, or none)
         if (cand) {
 #pragma unroll
@@ -159,9 +141,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
                 s_p[par][wave] = pm;
             }
         }
-        PH(2);  // candidate publish
         lds_barrier();
-        PH(3);  // barrier wait
         // global winner among <= 16 wave candidates: lane q < 16 takes candidate q, 4-step DPP fold inside the row
         double bv;
         int bp, bw;
@@ -192,7 +172,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
             bp = kmin >> 4;
             bw = kmin & 15;
         }
-        PH(4);  // scan
         const double pk = s_row[par][bw][0];
         if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
             if (t == 0) w.info[b] = kc + 1;
@@ -208,13 +187,12 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
             mypos = kc;
         }
         // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
-        if (wave == 0 && lane < NB && k + lane < wd && !(w.dbg & 64))
+        if (wave == 0 && lane < NB && k + lane < wd)
             A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
-        PH(5);  // pivot bookkeeping + row store
-        if (!owner && alive && !(w.dbg & 32)) {
+        if (!owner && alive) {
             if (mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
             const double aik = a[0] * s_row[par][bw][NB];
-            if (!(w.dbg & 64)) A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
+            A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
             const unsigned zm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_zm[par][bw]);
             if (zm == 0u) {
 #pragma unroll
@@ -236,7 +214,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
             }
             a[NB - 1] = 0.0;
         }
-        PH(6);  // update
     }
     if (failed) return;
 
@@ -252,117 +229,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     int base = 0;
     for (int q = 0; q < wave; ++q) base += s_cnt[q];
     if (alive) live[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
-#ifdef IDAHIP_STAMPS
-    PH(7);  // epilogue
-    if (lane == 0 && k0 == 0 && blockIdx.x < 8) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(w.ubuf) + ((long)blockIdx.x * NW + wave) * 8;
-        for (int i = 0; i < 8; ++i) o[i] = acc_[i];
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------ trsm (U12)
-template <int NB>
-__global__ __launch_bounds__(64) void lu_trsm_kernel(LuWs w, int k0) {
-    const int b = w.idx[blockIdx.x];
-    if (w.info[b] != 0) return;
-    const int n = w.n;
-    double* __restrict__ A = w.mats + (long)b * w.mstride;
-    const int* __restrict__ prow = w.prow + (long)b * n + k0;
-    const double* __restrict__ l11 = w.l11 + (long)b * NB * NB;
-    double* __restrict__ U = w.ubuf + (long)b * NB * w.npad16;
-    int* __restrict__ uz = w.uz + (long)b * (w.npad16 / 16);
-
-    const int lane = threadIdx.x;
-    const int c0 = k0 + NB + blockIdx.y * 64;  // only launched for full panels with a trailing matrix
-    const int jc = c0 + lane;
-    const bool valid = jc < n;
-    const bool inpad = jc < w.npad16;
-
-    double u[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) u[k] = valid ? A[(long)jc * n + ldc(prow + k)] : 0.0;
-
-    // Right-looking order over the source row kk: u[kk] is final once rows 0..kk-1 have been applied, and every target
-    // u[k], k > kk, still receives its updates in ascending kk. The a_kj == 0 skip (dense.rs:148) is per column
-    // (= per lane) here; one ballot per source row selects the unpredicated body when no lane holds a zero.
-    bool anyzero = !valid;
-#pragma unroll
-    for (int kk = 0; kk < NB; ++kk) {
-        const double ukk = u[kk];
-        const bool z = (ukk == 0.0);
-        anyzero = anyzero || z;
-        if (valid) A[(long)jc * n + ldc(prow + kk)] = ukk;
-        if (inpad) U[(long)kk * w.npad16 + jc] = ukk;
-        if (__ballot(z) == 0ull) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (k > kk) u[k] -= ukk * ldc(l11 + kk * NB + k);  // a(i,j) -= a_kj * a_ik
-        } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (k > kk) {
-                    const double t = u[k] - ukk * ldc(l11 + kk * NB + k);
-                    u[k] = z ? u[k] : t;
-                }
-        }
-    }
-    const unsigned long long bal = __ballot(anyzero);
-    if ((lane & 15) == 0 && inpad) uz[jc >> 4] = ((bal >> (lane & 48)) & 0xffffull) != 0ull;
-}
-
-// ------------------------------------------------------------------------------------------------ trailing update
-template <int NB>
-__global__ __launch_bounds__(256) void lu_update_kernel(LuWs w, int k0, int csplit) {
-    const int b = w.idx[blockIdx.x];
-    if (w.info[b] != 0) return;
-    const int n = w.n;
-    double* __restrict__ A = w.mats + (long)b * w.mstride;
-    const int* __restrict__ live = w.live + (long)b * n;
-    const double* __restrict__ Ub = w.ubuf + (long)b * NB * w.npad16;
-    const int* __restrict__ uz = w.uz + (long)b * (w.npad16 / 16);
-
-    const int mrem = n - k0 - NB;  // live rows after this panel
-    const int rt = blockIdx.y * 256 + threadIdx.x;
-    const int wave_first = blockIdx.y * 256 + (threadIdx.x & ~63);
-    if (wave_first >= mrem) return;  // whole wave idle
-    const bool valid = rt < mrem;
-    const int r = live[valid ? rt : (mrem - 1)];
-
-    double l[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) l[k] = A[(long)(k0 + k) * n + r];
-
-    const int cbeg = k0 + NB;
-    const int nchunks = (n - cbeg + 15) >> 4;
-    for (int ch = blockIdx.z; ch < nchunks; ch += csplit) {
-        const int c0 = cbeg + (ch << 4);
-        double c[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) c[j] = (c0 + j < n) ? A[(long)(c0 + j) * n + r] : 0.0;
-        const double* __restrict__ U = Ub + c0;
-        if (ldc(uz + (c0 >> 4)) == 0) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) c[j] -= ldc(U + (long)k * w.npad16 + j) * l[k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double ukj = ldc(U + (long)k * w.npad16 + j);
-                    if (ukj != 0.0) c[j] -= ukj * l[k];
-                }
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (c0 + j < n) A[(long)(c0 + j) * n + r] = c[j];
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ trailing (fused)
@@ -401,7 +267,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
     for (int pass = 0; pass < NB / 4; ++pass) {
         const int k = pass * 4 + wave;
         const int pr = ldc(prow + k);
-        Us[k][lane] = (lane < ncols && !(w.dbg & 4)) ? A[(long)(cb0 + lane) * n + pr] : 1.0;
+        Us[k][lane] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
     }
     if (t == 0) s_anyzero = 0;
     __syncthreads();
@@ -410,7 +276,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
     //    multipliers and the C tile of tile rt+1 are already in flight; one raw barrier per tile (LDS visibility only --
     //    a __syncthreads() would also drain the tile stores, which nobody in this launch reads).
     const int tx = t & 15, ty = t >> 4;
-    const int ntiles = (w.dbg & 2) ? 0 : ((mrem + 63) >> 6);
+    const int ntiles = (mrem + 63) >> 6;
     int col[4];
     bool cok[4];
 #pragma unroll
@@ -453,7 +319,6 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
             const double ukk = u[kk];
             const bool z = real && (ukk == 0.0);
             anyz = anyz || z;
-            if (w.dbg & 1) continue;
             if (__ballot(z) == 0ull) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
@@ -470,7 +335,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             Us[k][lane] = u[k];
-            if (real && !(w.dbg & 8)) A[(long)(cb0 + lane) * n + ldc(prow + k)] = u[k];
+            if (real) A[(long)(cb0 + lane) * n + ldc(prow + k)] = u[k];
         }
         if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
         load_tile(0, lreg, creg, crow, rok);
@@ -497,8 +362,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
             for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
         }
         if (rt + 1 < ntiles) load_tile(rt + 1, lreg, creg, crow, rok);  // in flight behind the arithmetic below
-        if (w.dbg & 16) {
-        } else if (!slow) {
+        if (!slow) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 double lv[4], uv[4];
@@ -600,28 +464,24 @@ __global__ void tiny_getrf_kernel(double* mats, long mstride, const int* idx, in
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
-// Factor the matrices `work[b]` (physical order, destroyed) of the listed systems into out[b] (reference layout).
+// Factor the matrices `work[b]` (column-major, physical row order, destroyed) of the listed systems into out[b]
+// (reference layout: rows at their pivoted positions). First-generation pipeline: panel(32) + fused trailing kernel.
 inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* out, long ostride, long long* piv, long pstride,
                              int* perm, const int* d_idx, int nsys) {
     const int n = c->n;
     if (nsys == 0) return 0;
     if (n <= TINY_N) {
-        // tiny path factors in place in `work`, then `out` is a plain copy if distinct
+        // tiny path factors in place in `work` (one thread per system, reference loops verbatim)
         hipLaunchKernelGGL(tiny_getrf_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, wstride, d_idx, nsys, n, piv,
                            pstride, perm, c->lu_info);
         return 0;
     }
     if (n > LU_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_MAX_N, n);
-    static const bool use_left = getenv("IDAHIP_LU_LEFT") != nullptr;    // A/B: one-launch left-looking kernel (lu_left.hpp)
-    static const bool use_split = getenv("IDAHIP_LU_SPLIT") != nullptr;  // A/B: separate trsm + scalar-operand update kernels
-    if (use_left) return lu_left_launch(c, work, wstride, out, ostride, piv, pstride, perm, d_idx, nsys);
     constexpr int NB = LU_NB;
     LuWs w;
-    w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n; w.npad16 = c->npad16;
+    w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info;
-    w.l11 = c->lu_l11; w.ubuf = c->lu_ubuf; w.uz = c->lu_uz;
-    static const int dbg = getenv("IDAHIP_LU_DBG") ? atoi(getenv("IDAHIP_LU_DBG")) : 0;
-    w.dbg = dbg;
+    w.l11 = c->lu_l11;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int m = n - k0;
@@ -631,19 +491,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         else
             hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
         const int ntrail = n - k0 - NB;
-        if (ntrail > 0) {
-            if (use_split) {
-                hipLaunchKernelGGL(lu_trsm_kernel<NB>, dim3(nsys, (c->npad16 - (k0 + NB) + 63) / 64), dim3(64), 0, c->stream, w, k0);
-                const int rowgroups = (ntrail + 255) / 256;
-                const int nchunks = (ntrail + 15) / 16;
-                int csplit = 1;
-                while ((long)nsys * rowgroups * csplit < 4096 && csplit < nchunks) csplit *= 2;
-                if (csplit > nchunks) csplit = nchunks;
-                hipLaunchKernelGGL(lu_update_kernel<NB>, dim3(nsys, rowgroups, csplit), dim3(256), 0, c->stream, w, k0, csplit);
-            } else {
-                hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys, (ntrail + 63) / 64), dim3(256), 0, c->stream, w, k0);
-            }
-        }
+        if (ntrail > 0) hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys, (ntrail + 63) / 64), dim3(256), 0, c->stream, w, k0);
     }
     const int cpb = 32;
     hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + cpb - 1) / cpb), dim3(256), 0, c->stream, w, out, ostride, perm, cpb);

@@ -31,7 +31,7 @@ HIP_SYMBOLS = [
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution",
-    "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset",
+    "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_solve",
@@ -97,6 +97,7 @@ def load():
     H.idahip_restore.argtypes = [vp, i32p, dp, i32p, ci]
     H.idahip_complete_step.argtypes = [vp, i32p, dp, ci, dp, i32p, i32p, ci]
     H.idahip_get_solution.argtypes = [vp, i32p, dp, dp, i32p, ci]
+    H.idahip_set_lu_variant.argtypes = [vp, ci]
     H.idahip_timing_enable.argtypes = [vp, ci]
     H.idahip_timing_get.argtypes = [vp, ci, dp, i64p, i64p]
     H.idahip_timing_reset.argtypes = [vp]
@@ -299,6 +300,9 @@ class Ctx:
         cvals = _f64(np.broadcast_to(cvals, (idx.size, 6)))
         dvals = _f64(np.broadcast_to(dvals, (idx.size, 5)))
         self._chk(self.H.idahip_get_solution(self.h, _p(kord, i32p), _p(cvals), _p(dvals), _p(idx, i32p), idx.size), "get_solution")
+
+    def set_lu_variant(self, variant):
+        self._chk(self.H.idahip_set_lu_variant(self.h, int(variant)), "set_lu_variant")
 
     # --- measurement
     def timing(self, on):

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 CNT = ("nst", "nre", "nje", "nsetups", "nni", "netf", "ncfn", "n_attempts")
 
 
-def run_gpu(prob, touts=None):
+def run_gpu(prob, touts=None, lu_variant=0):
     import idahip
     from idahip import problems
     ctx = problems.make_ctx(prob)
+    ctx.set_lu_variant(lu_variant)
     ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
     touts = prob["touts"] if touts is None else touts
     yy, yp = [], []
@@ -40,8 +41,8 @@ def run_oracle(prob, touts=None, nthreads=8):
                           params=prob.get("params"), A=prob.get("A"), B=prob.get("B"), c=prob.get("c"), nthreads=nthreads)
 
 
-def check(prob, touts=None):
-    ens, yy, yp = run_gpu(prob, touts)
+def check(prob, touts=None, lu_variant=0):
+    ens, yy, yp = run_gpu(prob, touts, lu_variant)
     ref = run_oracle(prob, touts)
     assert (ref["status"] == 0).all()
     c = ens.counters()
@@ -78,11 +79,12 @@ def test_lorenz63_ensemble():
     check(problems.lorenz63(batch=96), touts=0.1 * np.arange(1, 21))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n,batch", [(12, 6), (33, 5), (64, 8), (100, 4), (192, 3)])
-def test_linear_dense_ensemble(n, batch):
+def test_linear_dense_ensemble(n, batch, variant):
     from idahip import problems
     p = problems.linear_dense(n=n, batch=batch)
-    ens, ref = check(p)
+    ens, ref = check(p, lu_variant=variant)
     assert (ref["counters"]["nsetups"] > 1).all()  # stale-Jacobian iterations and re-factorisations both occurred
 
 
@@ -104,10 +106,11 @@ def test_linear_dense_trace_of_one_system():
     assert np.array_equal(tr, rec[:, :3])  # every accepted step: same t_n, h_used, order -- bit for bit
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n,batch", [(40, 4), (130, 3)])
-def test_heat1d_ensemble(n, batch):
+def test_heat1d_ensemble(n, batch, variant):
     from idahip import problems
-    check(problems.heat1d(n=n, batch=batch))
+    check(problems.heat1d(n=n, batch=batch), lu_variant=variant)
 
 
 def test_one_step_mode_and_interpolation_past_tout():

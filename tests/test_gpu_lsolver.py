@@ -18,10 +18,22 @@ def colmajor(mats):
     return np.ascontiguousarray(np.transpose(mats, (0, 2, 1)))
 
 
+LU_VARIANT = 0
+
+
+@pytest.fixture(params=[0, 1], ids=["lu-colmajor", "lu-rowmajor"], autouse=True)
+def lu_variant(request):
+    """Every test of this file runs against both factorisation pipelines."""
+    global LU_VARIANT
+    LU_VARIANT = request.param
+    yield
+
+
 def gpu_lu(mats, idx=None):
     import idahip
     B, n, _ = mats.shape
     ctx = idahip.Ctx("linear_dense" if n != 3 else "lorenz63", n, B)
+    ctx.set_lu_variant(LU_VARIANT)
     dA = ctx.dev_array(colmajor(mats))
     dP = ctx.dev_empty(8 * B * n)
     rc, info = ctx.ls_setup(dA, dP, idx)
