@@ -43,6 +43,31 @@ def algorithmic_bytes(n):
     }
 
 
+KERNEL_OF_CLASS = {
+    "lu": "batched getrf = lu_panel_kernel + lu_trail_kernel + lu_finalize_kernel launches of one idahip_nls_lsetup call",
+    "sys": "linear_sys_kernel", "newton_iter": "newton_iter_kernel", "jac": "linear_jac_kernel",
+}
+
+
+def profiled_traffic(cls):
+    """HBM bytes per system of the kernel class from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, gfx950-corrected; profiles/README.md). PMC counters cannot be read inside this process, so the
+    figure is the profiled one for the same command, or None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_w0_summary.json")
+    try:
+        s = json.load(open(path))
+    except Exception:
+        return None
+    names = {"lu": ("lu_panel_kernel", "lu_trail_kernel", "lu_finalize_kernel", "lu_init_kernel"), "sys": ("linear_sys_kernel",),
+             "newton_iter": ("newton_iter_kernel",), "jac": ("linear_jac_kernel",)}[cls]
+    tot = 0.0
+    for k, v in s["kernels"].items():
+        if k.startswith(names) and "hbm_read_GB_total" in v:
+            tot += v["hbm_read_GB_total"] + v["hbm_write_GB_total"]
+    systems = s["bench"]["kernel_classes_rank0"][cls]["systems"]
+    return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
+
+
 class Runner:
     """Continuous lock-step integration of config 3 with restart at t = 1."""
 
@@ -191,10 +216,13 @@ def main():
                        "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective"},
             "newton_iters_timed": iters_all,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": profiled_traffic(dom),
                          "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4),
-                         "algorithmic_bytes_per_system": ab[dom]},
+                         "algorithmic_bytes_per_system": ab[dom],
+                         "systems_per_launch": round(d["systems"] / max(1, d["launches"]), 1),
+                         "note": "achieved = algorithmic bytes of the systems processed / device time of the class (HIP events "
+                                 "on the ctx stream, timed region); for the LU the fp64 VALU ceiling binds before HBM (DESIGN.md section 4)"},
             "kernel_classes_rank0": classes,
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of a bench run (kernel stats + FETCH_SIZE / WRITE_SIZE PMC passes) into the per-kernel
+summary committed under profiles/. HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE / WRITE_SIZE are in KiB of 64-B requests; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced
+streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B-per-lane stores.
+usage: summarize_profiles.py <stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <bench.json> <out.json>"""
+import collections, csv, json, sys
+
+stats, fetch, write, bench, out = sys.argv[1:6]
+short = lambda n: n.split("(")[0].replace("void ", "").replace("idahip::", "")
+k = {}
+for r in csv.DictReader(open(stats)):
+    k[short(r["Name"])] = {"calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6, "avg_us": float(r["AverageNs"]) / 1e3,
+                           "pct": float(r["Percentage"])}
+def pmc(path, name):
+    acc, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            acc[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+            cnt[short(r["Kernel_Name"])] += 1
+    return acc, cnt
+f, fc = pmc(fetch, "FETCH_SIZE")
+w, wc = pmc(write, "WRITE_SIZE")
+for name, d in k.items():
+    if name in f:
+        d["hbm_read_GB_total"] = round(2.0 * f[name] * 1024 / 1e9, 3)   # gfx950 correction: x2
+        d["hbm_write_GB_total"] = round(w.get(name, 0.0) * 1024 / 1e9, 3)
+        d["hbm_bytes_per_launch"] = int((2.0 * f[name] + w.get(name, 0.0)) * 1024 / max(1, fc[name]))
+        d["hbm_GBps"] = round((2.0 * f[name] + w.get(name, 0.0)) * 1024 / 1e9 / (d["total_ms"] / 1e3), 1)
+b = json.load(open(bench))
+res = {"bench": {kk: b[kk] for kk in ("value", "steps", "warmup", "ms_per_step", "kernel_classes_rank0")}, "kernels": k,
+       "note": "kernel stats and PMC passes are separate runs of the same command (python3 bench.py --steps 40 --warmup 0 --no-cpu-baseline)"}
+json.dump(res, open(out, "w"), indent=1)
+for name, d in sorted(k.items(), key=lambda x: -x[1]["total_ms"])[:10]:
+    print("%-28s calls %5d total %9.2f ms avg %9.1f us  %s" % (name[:28], d["calls"], d["total_ms"], d["avg_us"],
+          ("read %.1f GB write %.1f GB -> %.0f GB/s" % (d["hbm_read_GB_total"], d["hbm_write_GB_total"], d["hbm_GBps"])) if "hbm_GBps" in d else ""))
+print(b["kernel_classes_rank0"])
