@@ -155,10 +155,18 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # Rehearsal knob for a one-GPU box: IDAHIP_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the barrier
+    # and the max-time (RCCL refuses two ranks on one device). Never set by the driver; the JSON line says so.
+    rehearse = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -184,7 +192,7 @@ def main():
     barrier()
     tim = run.ctx.timing_get()
 
-    elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cuda")
+    elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cpu" if rehearse else "cuda")
 
     if rank == 0:
         ab = algorithmic_bytes(args.n)
@@ -227,6 +235,8 @@ def main():
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
         }
+        if rehearse:
+            out["rehearsal"] = "all ranks on cuda:0 over gloo -- not a scaling measurement"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -36,8 +36,10 @@ struct LuWs {
     long long* piv;    // [batch][n] reference pivots (position chosen at step k)
     long pstride;      // elements between consecutive systems in piv
     int* info;         // [batch]   0 | 1-based zero-pivot column
-    double* l11;       // [batch][NB*NB] transposed L11: l11[kk*NB + k] = multiplier of the k-th pivot row for column kk
+    double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
+    int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
 };
+constexpr int L11_STRIDE = 64 * 64;  // elements per system in LuWs::l11
 
 __global__ void lu_init_kernel(LuWs w) {
     const int b = w.idx[blockIdx.x];
@@ -60,10 +62,10 @@ __global__ void lu_init_kernel(LuWs w) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NB, int MAXT, int WPE>
-__global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
+__global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int lbase) {
     constexpr int NW = MAXT / 64;
     constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
-    static_assert(NW <= 16 && NB == 32, "candidate scan assumes <= 16 waves, zero mask assumes NB == 32");
+    static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     int* __restrict__ live = w.live + (long)b * n;
     int* __restrict__ prow = w.prow + (long)b * n;
     long long* __restrict__ piv = w.piv + (long)b * w.pstride;
-    double* __restrict__ l11 = w.l11 + (long)b * NB * NB;
+    double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
 
     const int m = n - k0;
     const int wd = m < NB ? m : NB;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     __shared__ __align__(16) double s_row[2][NW][LDR];
     __shared__ __align__(16) double s_v[2][16];
     __shared__ __align__(16) int s_p[2][16];
-    __shared__ unsigned s_zm[2][NW];
+    __shared__ unsigned long long s_zm[2][NW];
     __shared__ int s_r[2][NW];
     __shared__ int s_cnt[NW];
 
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
         // zero mask of the candidate row (dense.rs:148): lanes 1..NB-1 re-read one entry each, one ballot
         {
             const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
-            const unsigned zm = (unsigned)(__ballot(lane > 0 && lane < NB && e == 0.0) & 0xffffffffull);
+            const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
             if (lane == 0) {
                 s_zm[par][wave] = zm;
                 s_v[par][wave] = vm;   // -1 when the wave has no live row
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
             if (mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
             const double aik = a[0] * s_row[par][bw][NB];
             A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
-            const unsigned zm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_zm[par][bw]);
-            if (zm == 0u) {
+            const unsigned long long zmv = s_zm[par][bw];
+            const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
+            if (zm == 0ull) {
 #pragma unroll
                 for (int jc = 0; jc < NB; jc += 8) {
                     double u[8];
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
                 }
             } else {
 #pragma unroll
-                for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1u) ? a[j] : a[j] - s_row[par][bw][j] * aik;
+                for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1ull) ? a[j] : a[j] - s_row[par][bw][j] * aik;
             }
             a[NB - 1] = 0.0;
         }
@@ -220,8 +224,19 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
     // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
     if (valid) pos[r] = mypos;
     __syncthreads();  // the multipliers stored above are visible to the whole workgroup
-    if (ownk > 0) {
-        for (int j = 0; j < ownk; ++j) l11[j * NB + ownk] = A[(long)(k0 + j) * n + r];  // [kk][k]: a TRSM step reads a contiguous run
+    // lbase = columns of the enclosing super-panel already factored by an earlier panel launch (0, or NB for the second
+    // half of a 2*NB super-panel): this pivot row's multipliers against those columns belong to the same L11
+    if (ownk >= 0) {
+        const int kq = lbase + ownk;
+        const double* __restrict__ src = A + (long)(k0 - lbase) * n + r;
+        for (int j0 = 0; j0 < kq; j0 += 8) {  // eight independent loads in flight, not one L2 round trip per multiplier
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (j0 + u < kq) ? src[(long)(j0 + u) * n] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < kq) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
+        }
     }
     const unsigned long long bal = __ballot(alive);
     if (lane == 0) s_cnt[wave] = __popcll(bal);
@@ -233,25 +248,31 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0) {
 
 // ------------------------------------------------------------------------------------------------ trailing (fused)
 // One workgroup per (matrix, block of 64 trailing columns): gathers the NB pivot rows of the block, solves
-// U12 = L11^-1 A12 in LDS (one wave, one column per lane, L11 through the scalar cache), writes the final U rows back,
+// U12 = L11^-1 A12 in LDS (one wave, one column per lane, L11 staged in LDS), writes the final U rows back,
 // then sweeps every 64-row tile of live rows with an LDS-tiled, register-blocked rank-NB update:
 //   256 threads = 16 x 16, each owning a 4 x 4 tile (rows tx+16i, columns ty+16j); per k the lane reads 4 multipliers
 //   and 4 U entries from LDS (conflict-free b64 reads) for 16 updates -> VALU-bound, ~100 VGPRs, 3 workgroups per CU.
 // No Ubuf round trip, no per-lane operand broadcast; the matrix is touched in coalesced column segments only
 // (the pivot-row gather/scatter is the one strided access: NB x 64 elements per workgroup).
 template <int NB>
-__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
-    const int b = w.idx[blockIdx.x];
+__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit) {
+    // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so the column blocks of one matrix are
+    // given ids with equal (id & 7) and adjacent (id >> 3): they run on one XCD at about the same time and share the
+    // multiplier panel L21 (read by every column block) through that XCD's L2 instead of re-reading it from HBM.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
+    if (mi >= nsys) return;
+    const int b = w.idx[mi];
     if (w.info[b] != 0) return;
     const int n = w.n;
     double* __restrict__ A = w.mats + (long)b * w.mstride;
     const int* __restrict__ live = w.live + (long)b * n;
     const int* __restrict__ prow = w.prow + (long)b * n + k0;
-    const double* __restrict__ l11 = w.l11 + (long)b * NB * NB;
+    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
 
     const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
-    const int cb0 = k0 + NB + blockIdx.y * 64;
-    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
+    const int cb0 = k0 + NB + cbi * 64;
+    const int ncols = (climit - cb0) < 64 ? (climit - cb0) : 64;  // climit = n, or the end of the super-panel for the narrow update
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
@@ -270,6 +291,9 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
         Us[k][lane] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
     }
     if (t == 0) s_anyzero = 0;
+    // transposed L11 into the (still idle) tile buffer: a triangular-solve step reads its multipliers as LDS broadcasts
+    // instead of waiting on one scalar load per step
+    for (int e = t; e < NB * NB; e += 256) Ls[0][e / NB][e % NB] = l11[(e / NB) * w.l11ld + (e % NB)];
     __syncthreads();
 
     // 3. rank-NB update of every 64-row tile of live rows, software-pipelined: while tile rt is computed from LDS the
@@ -322,12 +346,12 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
             if (__ballot(z) == 0ull) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
-                    if (k > kk) u[k] -= ukk * ldc(l11 + kk * NB + k);  // a(i,j) -= a_kj * a_ik, ascending kk
+                    if (k > kk) u[k] -= ukk * Ls[0][kk][k];  // a(i,j) -= a_kj * a_ik, ascending kk
             } else {
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
                     if (k > kk) {
-                        const double tn = u[k] - ukk * ldc(l11 + kk * NB + k);
+                        const double tn = u[k] - ukk * Ls[0][kk][k];
                         u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
                     }
             }
@@ -392,6 +416,233 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0) {
                     }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cok[j] && sok[i]) A[(long)col[j] * n + srow[i]] = c[i][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trailing, 64-wide panels
+// Same contract as lu_trail_kernel for panels of 64 columns (n <= 512): half as many sweeps over the trailing matrix,
+// so about half its HBM traffic. One workgroup per (matrix, 64 trailing columns):
+//   1. gather the 64 pivot rows of the block into LDS;
+//   2. U12 = L11^-1 A12 in three stages so that only two short chains are serial: wave 0 solves rows 0..31, all four
+//      waves apply those rows to rows 32..63 (8 rows per wave, multipliers through the scalar cache), wave 0 solves
+//      rows 32..63. Every element still receives its updates in ascending pivot order;
+//   3. rank-64 update of each 64-row tile of live rows as two k-chunks of 32 through one LDS multiplier buffer
+//      (49 KB of LDS per workgroup -> three workgroups per CU), 4 x 4 register tile per thread, the next tile's
+//      operands in flight behind the second chunk.
+__global__ __launch_bounds__(256, 3) void lu_trail64_kernel(LuWs w, int k0, int nsys, int ncb) {
+    constexpr int NB = 64, KC = 32, MAXROWS = LU_MAX_N;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
+    if (mi >= nsys) return;
+    const int b = w.idx[mi];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;
+    const int* __restrict__ live = w.live + (long)b * n;
+    const int* __restrict__ prow = w.prow + (long)b * n + k0;
+    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;  // l11ld == 64 here
+
+    const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
+    const int cb0 = k0 + NB + cbi * 64;
+    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    __shared__ __align__(16) double Us[NB][64];
+    __shared__ __align__(16) double Ls[KC][64];
+    __shared__ unsigned short s_live[MAXROWS];
+    __shared__ int s_anyzero;
+
+    for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+#pragma unroll
+    for (int pass = 0; pass < NB / 4; ++pass) {
+        const int k = pass * 4 + wave;
+        const int pr = ldc(prow + k);
+        Us[k][lane] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+    }
+    if (t == 0) s_anyzero = 0;
+    // L11 multipliers of pivot rows 0..31 (transposed: [source row kk][target row k]) into the idle tile buffer: a
+    // triangular-solve step then reads them as LDS broadcasts instead of waiting on one scalar load per step
+    auto stage_l11 = [&](const int R0) {
+#pragma unroll
+        for (int i = 0; i < (KC * 64) / 256; ++i) {
+            const int e = i * 256 + t;
+            Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
+        }
+    };
+    stage_l11(0);
+    lds_barrier();
+
+    const int tx = t & 15, ty = t >> 4;
+    const int ntiles = (mrem + 63) >> 6;
+    int col[4];
+    bool cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cj = ty + 16 * j;
+        cok[j] = cj < ncols;
+        col[j] = cb0 + (cok[j] ? cj : 0);
+    }
+    constexpr int LPT = KC / 4;  // multipliers per thread per k-chunk
+    double lreg[2][LPT], creg[4][4];
+    int crow[4];
+    bool rok[4];
+
+    auto load_tile = [&](int rt) {
+        const int lr = rt * 64 + lane;
+        const int lrow = s_live[lr < mrem ? lr : mrem - 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) lreg[h][i] = A[(long)(k0 + h * KC + wave * LPT + i) * n + lrow];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ri = rt * 64 + tx + 16 * i;
+            rok[i] = ri < mrem;
+            crow[i] = s_live[rok[i] ? ri : mrem - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) creg[i][j] = A[(long)col[j] * n + crow[i]];
+    };
+
+    // one triangular stage by wave 0: rows [R0, R0+32) of U12 against the diagonal block of L11 they share
+    auto trsm32 = [&](const int R0) {
+        double u[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) u[k] = Us[R0 + k][lane];
+        const bool real = lane < ncols;
+        bool anyz = false;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const double ukk = u[kk];
+            const bool z = real && (ukk == 0.0);
+            anyz = anyz || z;
+            if (__ballot(z) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k > kk) u[k] -= ukk * Ls[kk][R0 + k];  // a(i,j) -= a_kj * a_ik, ascending kk
+            } else {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k > kk) {
+                        const double tn = u[k] - ukk * Ls[kk][R0 + k];
+                        u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            Us[R0 + k][lane] = u[k];
+            if (real) A[(long)(cb0 + lane) * n + ldc(prow + R0 + k)] = u[k];
+        }
+        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
+    };
+
+    if (wave == 0) trsm32(0);
+    else load_tile(0);  // waves 1-3: live rows only (untouched by the U12 stores), in flight behind the triangular solves
+    lds_barrier();
+    {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
+        const bool zpath = s_anyzero != 0;
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = Us[KC + wave * 8 + i][lane];
+        if (!zpath) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const double ut = Us[kk][lane];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] -= ut * Ls[kk][KC + wave * 8 + i];
+            }
+        } else {
+#pragma unroll 4
+            for (int kk = 0; kk < KC; ++kk) {
+                const double ut = Us[kk][lane];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double tn = v[i] - ut * Ls[kk][KC + wave * 8 + i];
+                    v[i] = (ut != 0.0) ? tn : v[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Us[KC + wave * 8 + i][lane] = v[i];
+    }
+    lds_barrier();
+    stage_l11(KC);
+    lds_barrier();
+    if (wave == 0) {
+        trsm32(KC);
+        load_tile(0);
+    }
+    lds_barrier();
+    const bool slow = s_anyzero != 0;
+#ifdef T64_SKIP_TILES
+    if (k0 >= 0) return;
+#endif
+
+    auto chunk = [&](double (&c)[4][4], const int kbase) {
+        if (!slow) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Ls[k][tx + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][ty + 16 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < KC; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Ls[k][tx + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][ty + 16 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double tn = c[i][j] - uv[j] * lv[i];
+                        c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
+                    }
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int rt = 0; rt < ntiles; ++rt) {
+        lds_barrier();  // the previous tile's second chunk has been read by everyone
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) Ls[wave * LPT + i][lane] = lreg[0][i];
+        lds_barrier();
+        double c[4][4];
+        int srow[4];
+        bool sok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            srow[i] = crow[i];
+            sok[i] = rok[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
+        }
+        chunk(c, 0);
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) Ls[wave * LPT + i][lane] = lreg[1][i];
+        lds_barrier();
+        if (rt + 1 < ntiles) load_tile(rt + 1);  // in flight behind the second chunk
+        chunk(c, KC);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -477,21 +728,49 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         return 0;
     }
     if (n > LU_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_MAX_N, n);
-    constexpr int NB = LU_NB;
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info;
     w.l11 = c->lu_l11;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int m = n - k0;
-        const int threads = ((m + 63) / 64) * 64;
+    const int nsys8 = ((nsys + 7) / 8) * 8;
+    constexpr int NB = LU_NB;
+    auto panel = [&](int k0, int lbase) {
+        const int threads = ((n - k0 + 63) / 64) * 64;
         if (threads <= 512)
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+            hipLaunchKernelGGL((lu_panel_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
         else
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+            hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
+    };
+    if (c->lu_variant == 2) {
+        // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
+        // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
+        // kernel, the rest of the matrix sees both at once in the rank-64 kernel.
+        w.l11ld = 64;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            panel(k0, 0);
+            if (n - k0 > NB) {
+                const int cend = (k0 + 64 < n) ? k0 + 64 : n;
+                hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend);
+                panel(k0 + NB, NB);
+            }
+            const int ntrail = n - k0 - 64;
+            if (ntrail > 0) {
+                const int ncb = (ntrail + 63) / 64;
+                hipLaunchKernelGGL(lu_trail64_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+            }
+        }
+        hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32);
+        return 0;
+    }
+    w.l11ld = NB;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        panel(k0, 0);
         const int ntrail = n - k0 - NB;
-        if (ntrail > 0) hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys, (ntrail + 63) / 64), dim3(256), 0, c->stream, w, k0);
+        if (ntrail > 0) {
+            const int ncb = (ntrail + 63) / 64;
+            hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n);
+        }
     }
     const int cpb = 32;
     hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + cpb - 1) / cpb), dim3(256), 0, c->stream, w, out, ostride, perm, cpb);

@@ -21,9 +21,9 @@ def colmajor(mats):
 LU_VARIANT = 0
 
 
-@pytest.fixture(params=[0, 1], ids=["lu-colmajor", "lu-rowmajor"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["lu-colmajor", "lu-rowmajor", "lu-colmajor64"], autouse=True)
 def lu_variant(request):
-    """Every test of this file runs against both factorisation pipelines."""
+    """Every test of this file runs against every factorisation pipeline."""
     global LU_VARIANT
     LU_VARIANT = request.param
     yield
