@@ -57,7 +57,7 @@ struct idahip_ctx {
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr;
     double* lu_l11 = nullptr;
-    int lu_variant = 2;  // 0: column-major work matrix, 32-column panels + fused trailing kernel (lu_kernels.hpp)
+    int lu_variant = 3;  // 0: column-major work matrix, 32-column panels + fused trailing kernel (lu_kernels.hpp)
                          // 1: row-major work matrix, 16-column sub-panels, rank-64 trailing update (lu_rm.hpp)
 
     // problem data
@@ -226,6 +226,42 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     o = dpp_mov_i32<0x118, 0xf>(v); v = o < v ? o : v;
     o = dpp_mov_i32<0x142, 0xa>(v); v = o < v ? o : v;
     o = dpp_mov_i32<0x143, 0xc>(v); v = o < v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---- one-instruction DPP folds: the neutral element is the `old` operand (and bound_ctrl for the unsigned max), so the
+// compiler fuses the cross-lane move into v_max_u32_dpp / v_min_i32_dpp -- one VALU op per stage instead of six for a
+// double compare-and-select. ROWS16 = true stops after the row folds: every 16-lane row's result sits in its lane 15.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned x) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, true);
+    return o > x ? o : x;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imin(int x) {
+    const int o = __builtin_amdgcn_update_dpp(0x7fffffff, x, CTRL, ROW_MASK, 0xf, false);
+    return o < x ? o : x;
+}
+template <bool ROWS16>
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_umax<0x111, 0xf>(v);
+    v = dpp_umax<0x112, 0xf>(v);
+    v = dpp_umax<0x114, 0xf>(v);
+    v = dpp_umax<0x118, 0xf>(v);
+    if (ROWS16) return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+    v = dpp_umax<0x142, 0xa>(v);
+    v = dpp_umax<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <bool ROWS16>
+__device__ __forceinline__ int wave_min_i32f(int v) {
+    v = dpp_imin<0x111, 0xf>(v);
+    v = dpp_imin<0x112, 0xf>(v);
+    v = dpp_imin<0x114, 0xf>(v);
+    v = dpp_imin<0x118, 0xf>(v);
+    if (ROWS16) return __builtin_amdgcn_readlane(v, 15);
+    v = dpp_imin<0x142, 0xa>(v);
+    v = dpp_imin<0x143, 0xc>(v);
     return __builtin_amdgcn_readlane(v, 63);
 }
 

@@ -82,14 +82,15 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     __shared__ __align__(16) double s_row[2][NW][LDR];
-    __shared__ __align__(16) double s_v[2][16];
+    __shared__ unsigned s_kh[2][16], s_kl[2][16];
     __shared__ __align__(16) int s_p[2][16];
     __shared__ unsigned long long s_zm[2][NW];
     __shared__ int s_r[2][NW];
     __shared__ int s_cnt[NW];
 
     if (t < 32) {  // slots of waves that do not exist in this launch never win
-        (&s_v[0][0])[t] = -2.0;
+        (&s_kh[0][0])[t] = 0u;
+        (&s_kl[0][0])[t] = 0u;
         (&s_p[0][0])[t] = 0x7fffffff;
     }
     const bool valid = t < m;
@@ -104,24 +105,32 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int
     int ownk = -1;
     bool failed = false;
 
-#pragma unroll 1
-    for (int k = 0; k < wd; ++k) {
+    // one elimination step; returns false on a zero pivot. The column loop below runs two steps per trip so that the
+    // rotating row registers ping-pong between two sets instead of being copied back at every loop back-edge.
+    auto step = [&](const int k) -> bool {
         const int kc = k0 + k;
         const int par = k & 1;
-        // candidate key: (|a|, position); NaN only wins if it sits at position kc (dense.rs:111-117 scan semantics)
-        double v = -1.0;
-        int p = 0x7fffffff;
+        // candidate key of a live row: the bit pattern of |a| (monotone for non-negative doubles) with the always-clear
+        // sign bit set, so that 0 means "no candidate here"; ties go to the lowest position. NaN only wins if it sits
+        // at position kc (dense.rs:111-117 scan semantics).
+        unsigned kh = 0u, kl = 0u;
         if (alive) {
-            v = fabs(a[0]);
-            p = mypos;
-            if (v != v) v = (mypos == kc) ? __builtin_huge_val() : -1.0;
+            const double v = fabs(a[0]);
+            kh = (unsigned)__double2hiint(v) | 0x80000000u;
+            kl = (unsigned)__double2loint(v);
+            if (v != v) {
+                kh = (mypos == kc) ? 0xfff00000u : 0u;  // +inf, or never
+                kl = 0u;
+            }
         }
         // every lane forms the reciprocal of its own candidate pivot: the divide overlaps the reduction below instead
         // of sitting, single-lane, on the critical path of the winner.   mult = a(k,k).recip()  (dense.rs:134)
         const double myrecip = 1.0 / a[0];
-        const double vm = wave_max_f64(v);
-        const int pm = wave_min_i32(v == vm ? p : 0x7fffffff);
-        const bool cand = alive && p == pm && v == vm;  // this wave's candidate row (one lane, or none)
+        const unsigned mh = wave_max_u32<false>(kh);
+        const unsigned ml = wave_max_u32<false>(kh == mh ? kl : 0u);
+        const bool top = kh != 0u && kh == mh && kl == ml;
+        const int pm = wave_min_i32f<false>(top ? mypos : 0x7fffffff);
+        const bool cand = top && mypos == pm;  // this wave's candidate row (one lane, or none)
         if (cand) {
 #pragma unroll
             for (int j = 0; j < NB; j += 2) {
@@ -139,46 +148,30 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int
             const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
             if (lane == 0) {
                 s_zm[par][wave] = zm;
-                s_v[par][wave] = vm;   // -1 when the wave has no live row
+                s_kh[par][wave] = mh;  // 0 when the wave has no live row
+                s_kl[par][wave] = ml;
                 s_p[par][wave] = pm;
             }
         }
         lds_barrier();
         // global winner among <= 16 wave candidates: lane q < 16 takes candidate q, 4-step DPP fold inside the row
-        double bv;
         int bp, bw;
         {
             const int q = lane & 15;
-            double cv = s_v[par][q];
-            int cp = s_p[par][q];
-            // max |a|
-            double o;
-            double mv = cv;
-            o = dpp_mov_f64<0x111, 0xf>(mv); mv = o > mv ? o : mv;
-            o = dpp_mov_f64<0x112, 0xf>(mv); mv = o > mv ? o : mv;
-            o = dpp_mov_f64<0x114, 0xf>(mv); mv = o > mv ? o : mv;
-            o = dpp_mov_f64<0x118, 0xf>(mv); mv = o > mv ? o : mv;
-            bv = readlane_f64(mv, 15);
-            // lowest position among the candidates attaining it; the wave index rides in the low 4 bits of the key
-            long long key = (cv == bv) ? (((long long)cp << 4) | q) : 0x7fffffffffffffffll;
-            int klo = (int)(key & 0xffffffffll), khi = (int)(key >> 32);
-            // positions are < 2^27, so (pos << 4 | q) fits in 31 bits: compare the low word only
-            int kk_ = (cv == bv) ? ((cp << 4) | q) : 0x7fffffff;
-            (void)klo; (void)khi;
-            int oi;
-            oi = dpp_mov_i32<0x111, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
-            oi = dpp_mov_i32<0x112, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
-            oi = dpp_mov_i32<0x114, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
-            oi = dpp_mov_i32<0x118, 0xf>(kk_); kk_ = oi < kk_ ? oi : kk_;
-            const int kmin = __builtin_amdgcn_readlane(kk_, 15);
+            const unsigned ch = s_kh[par][q], cl = s_kl[par][q];
+            const int cp = s_p[par][q];
+            const unsigned bh = wave_max_u32<true>(ch);
+            const unsigned bl = wave_max_u32<true>(ch == bh ? cl : 0u);
+            // lowest position among the candidates attaining the maximum; the wave index rides in the low 4 bits of the
+            // key (positions are < 2^27, so (pos << 4 | q) fits in 31 bits)
+            const int kmin = wave_min_i32f<true>((ch == bh && cl == bl) ? ((cp << 4) | q) : 0x7fffffff);
             bp = kmin >> 4;
             bw = kmin & 15;
         }
         const double pk = s_row[par][bw][0];
         if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
             if (t == 0) w.info[b] = kc + 1;
-            failed = true;
-            break;
+            return false;
         }
         if (t == 0) piv[kc] = (long long)bp;
         const bool owner = alive && (mypos == bp);
@@ -191,34 +184,39 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int
         // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
         if (wave == 0 && lane < NB && k + lane < wd)
             A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
-        if (!owner && alive) {
-            if (mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
-            const double aik = a[0] * s_row[par][bw][NB];
-            A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
-            const unsigned long long zmv = s_zm[par][bw];
-            const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
-            if (zm == 0ull) {
+        // the arithmetic below runs on every lane (rows that are not live compute values nobody reads): no divergent
+        // region around the rotating registers, so the compiler updates them in place instead of copying all of them
+        const bool upd = !owner && alive;
+        if (upd && mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
+        const double aik = a[0] * s_row[par][bw][NB];
+        if (upd) A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
+        const unsigned long long zmv = s_zm[par][bw];
+        const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
+        if (zm == 0ull) {
 #pragma unroll
-                for (int jc = 0; jc < NB; jc += 8) {
-                    double u[8];
+            for (int jc = 0; jc < NB; jc += 8) {
+                double u[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
-                        u[j] = q.x;
-                        u[j + 1] = q.y;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (jc + j >= 1) a[jc + j - 1] = a[jc + j] - u[j] * aik;  // dense.rs:151, rotated one column
+                for (int j = 0; j < 8; j += 2) {
+                    const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
+                    u[j] = q.x;
+                    u[j + 1] = q.y;
                 }
-            } else {
 #pragma unroll
-                for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1ull) ? a[j] : a[j] - s_row[par][bw][j] * aik;
+                for (int j = 0; j < 8; ++j)
+                    if (jc + j >= 1) a[jc + j - 1] = a[jc + j] - u[j] * aik;  // dense.rs:151, rotated one column
             }
-            a[NB - 1] = 0.0;
+        } else {
+#pragma unroll
+            for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1ull) ? a[j] : a[j] - s_row[par][bw][j] * aik;
         }
-    }
+        a[NB - 1] = 0.0;
+        return true;
+    };
+#pragma unroll 1
+    for (int k = 0; k < wd; ++k)
+        if (!step(k)) { failed = true; break; }
     if (failed) return;
 
     // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
@@ -244,6 +242,242 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int
     int base = 0;
     for (int q = 0; q < wave; ++q) base += s_cnt[q];
     if (alive) live[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ panel, two rows per thread
+// Same contract as lu_panel_kernel. A step of the panel is one long dependent chain (arg-max -> LDS -> barrier ->
+// winner scan -> LDS -> update) of ~450 instructions per wave whatever the number of rows a lane carries; with two
+// live rows per lane (row t and row t + T of the live list) the same chain serves twice the rows, the wave count per
+// matrix halves, and two matrices share a CU where one used to sit (~190 VGPRs: 2 x 32 panel entries per lane).
+template <int NB, int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, int lbase) {
+    constexpr int R = 2;
+    constexpr int NW = MAXT / 64;
+    constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
+    static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
+    const int b = w.idx[blockIdx.x];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;
+    int* __restrict__ pos = w.pos + (long)b * n;
+    int* __restrict__ live = w.live + (long)b * n;
+    int* __restrict__ prow = w.prow + (long)b * n;
+    long long* __restrict__ piv = w.piv + (long)b * w.pstride;
+    double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
+
+    const int m = n - k0;
+    const int wd = m < NB ? m : NB;
+    const int T = blockDim.x;  // R * T >= m
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    __shared__ __align__(16) double s_row[2][NW][LDR];
+    __shared__ unsigned s_kh[2][16], s_kl[2][16];
+    __shared__ __align__(16) int s_p[2][16];
+    __shared__ unsigned long long s_zm[2][NW];
+    __shared__ int s_r[2][NW];
+    __shared__ int s_cnt[R][NW];
+
+    if (t < 32) {  // slots of waves that do not exist in this launch never win
+        (&s_kh[0][0])[t] = 0u;
+        (&s_kl[0][0])[t] = 0u;
+        (&s_p[0][0])[t] = 0x7fffffff;
+    }
+    bool valid[R], alive[R];
+    int r[R], mypos[R], ownk[R];
+    double a[R][NB];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int li = t + i * T;
+        valid[i] = li < m;
+        alive[i] = valid[i];
+        ownk[i] = -1;
+        r[i] = valid[i] ? live[li] : 0;
+        mypos[i] = valid[i] ? pos[r[i]] : 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[i][j] = (valid[i] && j < wd) ? A[(long)(k0 + j) * n + r[i]] : 0.0;
+    }
+    __syncthreads();
+
+    bool failed = false;
+    auto step = [&](const int k) -> bool {
+        const int kc = k0 + k;
+        const int par = k & 1;
+        // candidate key of a live row: the bit pattern of |a| with the always-clear sign bit set (0 = no candidate);
+        // ties go to the lowest position; NaN only wins at position kc (dense.rs:111-117 scan semantics)
+        unsigned kh[R], kl[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            kh[i] = 0u;
+            kl[i] = 0u;
+            if (alive[i]) {
+                const double v = fabs(a[i][0]);
+                kh[i] = (unsigned)__double2hiint(v) | 0x80000000u;
+                kl[i] = (unsigned)__double2loint(v);
+                if (v != v) {
+                    kh[i] = (mypos[i] == kc) ? 0xfff00000u : 0u;
+                    kl[i] = 0u;
+                }
+            }
+        }
+        // the better of the lane's own two rows
+        const bool s1 = kh[1] > kh[0] || (kh[1] == kh[0] && (kl[1] > kl[0] || (kl[1] == kl[0] && mypos[1] < mypos[0])));
+        const unsigned bkh = s1 ? kh[1] : kh[0], bkl = s1 ? kl[1] : kl[0];
+        const int bpos = s1 ? mypos[1] : mypos[0];
+        const double myrecip = 1.0 / (s1 ? a[1][0] : a[0][0]);  // mult = a(k,k).recip() (dense.rs:134), off the critical path
+        const unsigned mh = wave_max_u32<false>(bkh);
+        const unsigned ml = wave_max_u32<false>(bkh == mh ? bkl : 0u);
+        const bool top = bkh != 0u && bkh == mh && bkl == ml;
+        const int pm = wave_min_i32f<false>(top ? bpos : 0x7fffffff);
+        const bool cand = top && bpos == pm;  // this wave's candidate row (one lane, or none)
+        if (cand && !s1) {
+#pragma unroll
+            for (int j = 0; j < NB; j += 2) {
+                double2 q;
+                q.x = a[0][j];
+                q.y = a[0][j + 1];
+                *reinterpret_cast<double2*>(&s_row[par][wave][j]) = q;
+            }
+            s_r[par][wave] = r[0];
+        }
+        if (cand && s1) {
+#pragma unroll
+            for (int j = 0; j < NB; j += 2) {
+                double2 q;
+                q.x = a[1][j];
+                q.y = a[1][j + 1];
+                *reinterpret_cast<double2*>(&s_row[par][wave][j]) = q;
+            }
+            s_r[par][wave] = r[1];
+        }
+        if (cand) s_row[par][wave][NB] = myrecip;
+        {   // zero mask of the candidate row (dense.rs:148): one entry per lane, one ballot
+            const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
+            const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
+            if (lane == 0) {
+                s_zm[par][wave] = zm;
+                s_kh[par][wave] = mh;  // 0 when the wave has no live row
+                s_kl[par][wave] = ml;
+                s_p[par][wave] = pm;
+            }
+        }
+        lds_barrier();
+        int bp, bw;
+        {
+            const int q = lane & 15;
+            const unsigned ch = s_kh[par][q], cl = s_kl[par][q];
+            const int cp = s_p[par][q];
+            const unsigned bh = wave_max_u32<true>(ch);
+            const unsigned bl = wave_max_u32<true>(ch == bh ? cl : 0u);
+            const int kmin = wave_min_i32f<true>((ch == bh && cl == bl) ? ((cp << 4) | q) : 0x7fffffff);
+            bp = kmin >> 4;
+            bw = kmin & 15;
+        }
+        const double pk = s_row[par][bw][0];
+        if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
+            if (t == 0) w.info[b] = kc + 1;
+            return false;
+        }
+        if (t == 0) piv[kc] = (long long)bp;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (alive[i] && mypos[i] == bp) {  // this row is the pivot
+                prow[kc] = r[i];
+                ownk[i] = k;
+                alive[i] = false;
+                mypos[i] = kc;
+            } else if (alive[i] && mypos[i] == kc) {
+                mypos[i] = bp;  // the row that sat at position k moves to the pivot's old position
+            }
+        }
+        // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
+        if (wave == 0 && lane < NB && k + lane < wd)
+            A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
+        const double recip = s_row[par][bw][NB];
+        double aik[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            aik[i] = a[i][0] * recip;
+            if (alive[i]) A[(long)kc * n + r[i]] = aik[i];  // the multiplier is final (coalesced column store)
+        }
+        const unsigned long long zmv = s_zm[par][bw];
+        const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
+        // the arithmetic runs on every lane (rows that are not live compute values nobody reads)
+        if (zm == 0ull) {
+#pragma unroll
+            for (int jc = 0; jc < NB; jc += 8) {
+                double u[8];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
+                    u[j] = q.x;
+                    u[j + 1] = q.y;
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (jc + j >= 1) a[i][jc + j - 1] = a[i][jc + j] - u[j] * aik[i];  // dense.rs:151, rotated one column
+                __builtin_amdgcn_sched_barrier(0);  // keep the pivot-row reads of later chunks from piling up in registers
+            }
+        } else {
+#pragma unroll
+            for (int j = 1; j < NB; ++j) {
+                const double uj = s_row[par][bw][j];
+#pragma unroll
+                for (int i = 0; i < R; ++i) a[i][j - 1] = ((zm >> j) & 1ull) ? a[i][j] : a[i][j] - uj * aik[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) a[i][NB - 1] = 0.0;
+        return true;
+    };
+#pragma unroll 1
+    for (int k = 0; k < wd; ++k)
+        if (!step(k)) { failed = true; break; }
+    if (failed) return;
+
+    // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (valid[i]) pos[r[i]] = mypos[i];
+    __syncthreads();  // the multipliers stored above are visible to the whole workgroup
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (ownk[i] >= 0) {
+            const int kq = lbase + ownk[i];  // index of this pivot row inside the enclosing super-panel
+            const double* __restrict__ src = A + (long)(k0 - lbase) * n + r[i];
+            for (int j0 = 0; j0 < kq; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (j0 + u < kq) ? src[(long)(j0 + u) * n] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < kq) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
+            }
+        }
+    }
+    // live list: the surviving rows of set 0 in thread order, then those of set 1 (the list stays sorted)
+    unsigned long long bal[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        bal[i] = __ballot(alive[i]);
+        if (lane == 0) s_cnt[i][wave] = __popcll(bal[i]);
+    }
+    __syncthreads();
+    const int nwaves = T >> 6;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        int mine = base;
+        for (int q = 0; q < nwaves; ++q) {
+            const int c = s_cnt[i][q];
+            if (q < wave) mine += c;
+            base += c;
+        }
+        if (alive[i]) live[mine + __popcll(bal[i] & ((1ull << lane) - 1ull))] = r[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ trailing (fused)
@@ -742,17 +976,22 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         else
             hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    if (c->lu_variant == 2) {
+    auto panel2 = [&](int k0, int lbase) {  // two rows per lane: half the threads
+        const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
+        hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
+    };
+    const bool two_rows = c->lu_variant == 3;
+    if (c->lu_variant == 2 || c->lu_variant == 3) {
         // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
         // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
         // kernel, the rest of the matrix sees both at once in the rank-64 kernel.
         w.l11ld = 64;
         for (int k0 = 0; k0 < n; k0 += 64) {
-            panel(k0, 0);
+            if (two_rows) panel2(k0, 0); else panel(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
                 hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend);
-                panel(k0 + NB, NB);
+                if (two_rows) panel2(k0 + NB, NB); else panel(k0 + NB, NB);
             }
             const int ntrail = n - k0 - 64;
             if (ntrail > 0) {
