@@ -44,7 +44,7 @@ def algorithmic_bytes(n):
 
 
 KERNEL_OF_CLASS = {
-    "lu": "batched getrf = lu_panel_kernel + lu_trail_kernel + lu_finalize_kernel launches of one idahip_nls_lsetup call",
+    "lu": "batched getrf = the lu_panel2 / lu_trail / lu_trail64 / lu_finalize kernel launches of one idahip_nls_lsetup call",
     "sys": "linear_sys_kernel", "newton_iter": "newton_iter_kernel", "jac": "linear_jac_kernel",
 }
 
@@ -58,7 +58,7 @@ def profiled_traffic(cls):
         s = json.load(open(path))
     except Exception:
         return None
-    names = {"lu": ("lu_panel_kernel", "lu_trail_kernel", "lu_finalize_kernel", "lu_init_kernel"), "sys": ("linear_sys_kernel",),
+    names = {"lu": ("lu_",), "sys": ("linear_sys_kernel",),
              "newton_iter": ("newton_iter_kernel",), "jac": ("linear_jac_kernel",)}[cls]
     tot = 0.0
     for k, v in s["kernels"].items():

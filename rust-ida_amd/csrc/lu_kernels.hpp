@@ -12,12 +12,16 @@
 //     position it occupies in the reference's (explicitly swapped) matrix; the argmax key is (|a|, pos) so ties
 //     resolve exactly as the reference's scan does. Column-major storage makes physical row swaps a strided,
 //     uncoalesced disaster on a GPU; here every access is a coalesced column segment.
-//   * right-looking blocked algorithm, panel width NB, three kernels per panel step over the whole list of
-//     matrices (lock-step batch, hundreds to thousands of workgroups per launch):
-//       lu_panel  : one workgroup per matrix, one live row per thread, the row's NB panel entries in registers;
-//                   wave-shuffle + LDS arg-max, pivot row broadcast through LDS.
-//       lu_trail  : per (matrix, 64 columns): pivot-row gather, U12 = L11^-1 A12 in LDS (L11 through the scalar
-//                   cache), then A22 -= L21 U12 on 64x64 tiles, 4x4 register tile per thread, operands from LDS.
+//   * right-looking blocked algorithm over the whole list of matrices (lock-step batch, thousands of workgroups per
+//     launch). Default pipeline (LU variant 3), per 64-column super-panel:
+//       lu_panel2 (k0)      : one workgroup per matrix, two live rows per lane, 32 panel entries per row in registers;
+//                             fused-DPP + LDS arg-max, pivot row broadcast through LDS;
+//       lu_trail<32> narrow : the first panel's update of the super-panel's other 32 columns;
+//       lu_panel2 (k0 + 32) : second half of the super-panel;
+//       lu_trail64          : per (matrix, 64 trailing columns): pivot-row gather, U12 = L11^-1 A12 in LDS, then
+//                             A22 -= L21 U12 on 64x64 tiles, rank 64, 4x4 register tile per thread, operands from LDS.
+//     Variants 0 and 2 (one row per lane: lu_panel; 32-column panels with a rank-32 lu_trail) are the earlier pipelines,
+//     kept for A/B measurements and as cross-checks in the tests.
 //   * a final pass scatters rows to their pivoted positions (the reference layout the solve kernels stream).
 // Blocking changes neither the per-element operation order nor any operand, only when each update is applied.
 #pragma once
