@@ -889,6 +889,234 @@ __global__ __launch_bounds__(256, 3) void lu_trail64_kernel(LuWs w, int k0, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ trailing, 64-wide panels, wave-private strips
+// lu_trail64_kernel with a different split of the tile work: a wave owns 16-row strips of the block (64 columns wide) and
+// stages the multipliers of ITS rows in its own 4 KB of LDS, so the update loop has no workgroup barrier at all -- waves
+// only meet in the U12 prologue. Per lane a 4 x 4 register tile (rows a + 4i of the strip, columns q + 16j); L and U are
+// stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU ops.
+__global__ __launch_bounds__(256, 3) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
+    constexpr int NB = 64, KC = 32, MAXROWS = LU_MAX_N;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
+    if (mi >= nsys) return;
+    const int b = w.idx[mi];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;
+    const int* __restrict__ live = w.live + (long)b * n;
+    const int* __restrict__ prow = w.prow + (long)b * n + k0;
+    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;  // l11ld == 64 here
+
+    const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
+    const int cb0 = k0 + NB + cbi * 64;
+    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pl = 4 * (lane & 15) + (lane >> 4);  // LDS slot of column `lane`: columns q, q+16, q+32, q+48 sit together
+
+    __shared__ __align__(16) double Us[NB][64];      // U12, columns permuted by pl
+    __shared__ __align__(16) double Ls[KC][64];      // prologue: L11 staging; update loop: 4 wave-private [KC][16] strips
+    __shared__ unsigned short s_live[MAXROWS];
+    __shared__ int s_anyzero;
+
+    for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+#pragma unroll
+    for (int pass = 0; pass < NB / 4; ++pass) {
+        const int k = pass * 4 + wave;
+        const int pr = ldc(prow + k);
+        Us[k][pl] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+    }
+    if (t == 0) s_anyzero = 0;
+    auto stage_l11 = [&](const int R0) {
+#pragma unroll
+        for (int i = 0; i < (KC * 64) / 256; ++i) {
+            const int e = i * 256 + t;
+            Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
+        }
+    };
+    stage_l11(0);
+    lds_barrier();
+
+    // ---- this lane's share of a strip: rows a + 4i, columns q + 16j
+    const int a = lane & 3, q = lane >> 2;
+    const int nstrips = (mrem + 15) >> 4;
+    int coff[4];
+    bool cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cj = q + 16 * j;
+        cok[j] = cj < ncols;
+        coff[j] = (cb0 + (cok[j] ? cj : 0)) * n;
+    }
+    constexpr int LPT = KC / 4;  // multipliers per lane per k-chunk: lane (kq = lane >> 4, row = lane & 15) loads k = 4i + kq
+    const int kq = lane >> 4, lr16 = lane & 15;
+    const int lslot = 4 * (lr16 & 3) + (lr16 >> 2);  // rows a, a+4, a+8, a+12 of the strip sit together
+    double lreg[LPT], creg[4][4];
+    int crow[4];
+    bool rok[4];
+
+    auto load_L = [&](int s, int h) {  // one k-chunk of the strip's multipliers
+        const int lr = s * 16 + lr16;
+        const int lrow = s_live[lr < mrem ? lr : mrem - 1];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) lreg[i] = A[(k0 + h * KC + 4 * i + kq) * n + lrow];
+    };
+    auto load_C = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ri = s * 16 + a + 4 * i;
+            rok[i] = ri < mrem;
+            crow[i] = s_live[rok[i] ? ri : mrem - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) creg[i][j] = A[coff[j] + crow[i]];
+    };
+
+    // one triangular stage by wave 0: rows [R0, R0+32) of U12 against the diagonal block of L11 they share
+    auto trsm32 = [&](const int R0) {
+        double u[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) u[k] = Us[R0 + k][pl];
+        const bool real = lane < ncols;
+        bool anyz = false;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const double ukk = u[kk];
+            const bool z = real && (ukk == 0.0);
+            anyz = anyz || z;
+            if (__ballot(z) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k > kk) u[k] -= ukk * Ls[kk][R0 + k];  // a(i,j) -= a_kj * a_ik, ascending kk
+            } else {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k > kk) {
+                        const double tn = u[k] - ukk * Ls[kk][R0 + k];
+                        u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            Us[R0 + k][pl] = u[k];
+            if (real) A[(long)(cb0 + lane) * n + ldc(prow + R0 + k)] = u[k];
+        }
+        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
+    };
+
+    if (wave == 0) trsm32(0);
+    else if (wave < nstrips) {  // live rows only (untouched by the U12 stores), in flight behind the solves
+        load_C(wave);
+        load_L(wave, 0);
+    }
+    lds_barrier();
+    {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
+        const bool zpath = s_anyzero != 0;
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = Us[KC + wave * 8 + i][pl];
+        if (!zpath) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const double ut = Us[kk][pl];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] -= ut * Ls[kk][KC + wave * 8 + i];
+            }
+        } else {
+#pragma unroll 4
+            for (int kk = 0; kk < KC; ++kk) {
+                const double ut = Us[kk][pl];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double tn = v[i] - ut * Ls[kk][KC + wave * 8 + i];
+                    v[i] = (ut != 0.0) ? tn : v[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Us[KC + wave * 8 + i][pl] = v[i];
+    }
+    lds_barrier();
+    stage_l11(KC);
+    lds_barrier();
+    if (wave == 0) {
+        trsm32(KC);
+        if (0 < nstrips) {
+            load_C(0);
+            load_L(0, 0);
+        }
+    }
+    lds_barrier();  // last workgroup barrier: from here on a wave touches only Us (read-only) and its own strip of Ls
+    const bool slow = s_anyzero != 0;
+    double (*__restrict__ Lw)[16] = reinterpret_cast<double (*)[16]>(&Ls[0][0] + wave * (KC * 16));
+
+    auto chunk = [&](double (&c)[4][4], const int kbase) {
+        if (!slow) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Lw[k][4 * a + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][4 * q + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < KC; ++k) {
+                double lv[4], uv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lv[i] = Lw[k][4 * a + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][4 * q + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double tn = c[i][j] - uv[j] * lv[i];
+                        c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
+                    }
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int s = wave; s < nstrips; s += 4) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];
+        load_L(s, 1);  // the strip's second k-chunk, in flight behind the first chunk's arithmetic
+        double c[4][4];
+        int srow[4];
+        bool sok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            srow[i] = crow[i];
+            sok[i] = rok[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
+        }
+        chunk(c, 0);
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];  // same wave, program order: chunk 0's reads are done
+        if (s + 4 < nstrips) {  // next strip in flight behind the second chunk
+            load_C(s + 4);
+            load_L(s + 4, 0);
+        }
+        chunk(c, KC);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cok[j] && sok[i]) A[coff[j] + srow[i]] = c[i][j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ finalize
 // out(pos[r], j) = work(r, j); perm[pos[r]] = r. One workgroup per (matrix, column group).
 __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __restrict__ out, long ostride, int* __restrict__ perm,
@@ -984,8 +1212,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    const bool two_rows = c->lu_variant == 3;
-    if (c->lu_variant == 2 || c->lu_variant == 3) {
+    const bool two_rows = c->lu_variant >= 3;
+    if (c->lu_variant >= 2) {
         // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
         // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
         // kernel, the rest of the matrix sees both at once in the rank-64 kernel.
@@ -1000,7 +1228,10 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             const int ntrail = n - k0 - 64;
             if (ntrail > 0) {
                 const int ncb = (ntrail + 63) / 64;
-                hipLaunchKernelGGL(lu_trail64_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                if (c->lu_variant == 4)
+                    hipLaunchKernelGGL(lu_trail64w_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                else
+                    hipLaunchKernelGGL(lu_trail64_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             }
         }
         hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32);

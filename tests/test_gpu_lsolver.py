@@ -21,7 +21,7 @@ def colmajor(mats):
 LU_VARIANT = 0
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["lu-colmajor", "lu-rowmajor", "lu-colmajor64", "lu-colmajor64-2rows"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["lu-colmajor", "lu-rowmajor", "lu-colmajor64", "lu-colmajor64-2rows", "lu-colmajor64-strips"], autouse=True)
 def lu_variant(request):
     """Every test of this file runs against every factorisation pipeline."""
     global LU_VARIANT
