@@ -127,10 +127,11 @@ int idahip_complete_step(idahip_ctx* ctx, const int32_t* hKused, const double* h
 int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCvals, const double* hDvals,
                         const int32_t* hIdx, int nsys);
 
-/* LU implementation choice (all bit-identical to dense_get_rf): 3 = default: column-major work
- * matrix, 64-column super-panels built from two 32-column panels with two rows per lane, rank-64 trailing update;
- * 2 = the same with one row per lane in the panel kernel; 0 = 32-column panels and rank-32 trailing update; 1 = row-major
- * work matrix with 16-column sub-panels. 0-2 are kept for A/B measurements and as cross-checks in the tests. */
+/* LU implementation choice (all bit-identical to dense_get_rf): 4 = default: column-major work
+ * matrix, 64-column super-panels built from two 32-column panels with two rows per lane, rank-64 trailing update in
+ * wave-private 16-row strips; 3 = the same with workgroup-wide 64-row tiles; 2 = as 3 with one row per lane in the panel
+ * kernel; 0 = 32-column panels and rank-32 trailing update; 1 = row-major work matrix with 16-column sub-panels.
+ * 0-3 are kept for A/B measurements and as cross-checks in the tests. */
 int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
 
 /* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the
