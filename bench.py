@@ -68,8 +68,8 @@ def profiled_traffic(cls):
     return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
 
 
-class Runner:
-    """Continuous lock-step integration of config 3 with restart at t = 1."""
+class Lane:
+    """Continuous lock-step integration of one contiguous slice of the rank's systems, with restart at t = 1."""
 
     def __init__(self, prob, device):
         import idahip
@@ -107,6 +107,67 @@ class Runner:
                 self._new_ensemble()
 
 
+class Runner:
+    """The rank's batch as `lanes` contiguous slices, each with its own device context and stream, stepped together: a
+    step is one lock-step round of every slice, i.e. of the whole batch. With lanes > 1 the slices run from their own
+    host threads (the C ABI releases the GIL), so the host-side control of one slice overlaps the device work of the
+    others, and the latency-bound panel kernels of one slice overlap the throughput-bound kernels of another."""
+
+    def __init__(self, prob, device, lanes=1):
+        import threading
+        batch = prob["yy0"].shape[0]
+        edges = [batch * i // lanes for i in range(lanes + 1)]
+        self.lanes = []
+        for i in range(lanes):
+            lo, hi = edges[i], edges[i + 1]
+            sub = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == batch else v) for k, v in prob.items()}
+            self.lanes.append(Lane(sub, device))
+        self._threading = threading
+
+    def total_iters(self):
+        return sum(l.total_iters() for l in self.lanes)
+
+    def step(self):
+        if len(self.lanes) == 1:
+            self.lanes[0].step()
+            return
+        errs = []
+
+        def run(l):
+            try:
+                l.step()
+            except Exception as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                errs.append(e)
+        th = [self._threading.Thread(target=run, args=(l,)) for l in self.lanes]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+
+    def sync(self):
+        for l in self.lanes:
+            l.ctx._chk(l.ctx.H.idahip_sync(l.ctx.h), "sync")
+
+    def timing(self, on):
+        for l in self.lanes:
+            l.ctx.timing(on)
+            l.ctx.timing_reset()
+
+    def timing_get(self):
+        tot = None
+        for l in self.lanes:
+            t = l.ctx.timing_get()
+            if tot is None:
+                tot = t
+            else:
+                for k, v in t.items():
+                    for kk in v:
+                        tot[k][kk] += v[kk]
+        return tot
+
+
 def cpu_baseline(prob_small, cores):
     """The reference's CPU path as restated in oracle/ (kind = "port"), timed on this host's cores on a bounded sample of
     the same workload: the first len(sample) systems of config 3, integrated t = 0 -> 1 like the GPU run."""
@@ -127,6 +188,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--batch", type=int, default=4096, help="systems per GPU")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("IDAHIP_BENCH_LANES", "1")),
+                    help="slices of the rank's batch stepped concurrently on their own streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,24 +236,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(prob, local_rank)
+    run = Runner(prob, local_rank, lanes=args.lanes)
     del prob["A"], prob["B"]  # host copies no longer needed
 
     for _ in range(args.warmup):
         run.step()
-    run.ctx.timing(True)
-    run.ctx.timing_reset()
+    run.timing(True)
     barrier()
     it0 = run.total_iters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.step()
-    run.ctx._chk(run.ctx.H.idahip_sync(run.ctx.h), "sync")
+    run.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     iters = run.total_iters() - it0
     barrier()
-    tim = run.ctx.timing_get()
+    tim = run.timing_get()
 
     elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cpu" if rehearse else "cuda")
 
@@ -222,7 +284,8 @@ def main():
             "config": {"workload": "random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, "
                                    "rtol 1e-6 atol 1e-8, t=0..1 in 10 solve calls, restart at t=1" % (args.n, args.batch),
                        "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
-                       "sharding": "independent systems, contiguous block per rank, no collective"},
+                       "sharding": "independent systems, contiguous block per rank, no collective",
+                       "lanes_per_gpu": args.lanes},
             "newton_iters_timed": iters_all,
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": profiled_traffic(dom),

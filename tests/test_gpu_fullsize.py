@@ -1,0 +1,107 @@
+"""Parity at BASELINE.json's full single-GPU size (config 3: N = 512, B = 4096 systems resident on one device).
+
+The oracle cannot integrate 4096 systems of N = 512 in test time, so the full-size run is checked through properties that
+do not depend on the batch size, plus the oracle itself on a sample:
+  * a sample of systems spread over the batch is bit-identical (state, step sizes, orders, every counter) to the
+    oracle integrating those systems alone;
+  * batch-position independence: the same systems integrated as a small batch of their own give the same bits as
+    inside the full batch (no cross-talk between workgroups, index lists, staging rings);
+  * the batched LU of all 4096 Jacobians satisfies P J = L U to rounding on sampled systems and its forward/back
+    substitution solves J x = b; the factors of the sampled systems are bit-identical to the oracle's.
+Input generation (17 GB) dominates the run time; everything shares one module-scoped fixture.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+N, B = 512, 4096
+SAMPLE = np.array([0, 1, 63, 64, 777, 1023, 1024, 2047, 2048, 3000, 4094, 4095])
+CNT = ("nst", "nre", "nje", "nsetups", "nni", "netf", "ncfn", "n_attempts")
+
+
+@pytest.fixture(scope="module")
+def full():
+    import idahip
+    from idahip import problems
+    # forked numpy workers (fork, no exec; the children never touch the GPU and leave through os._exit)
+    procs = max(1, min(32, (os.cpu_count() or 1) // 2))
+    prob = problems.linear_dense(n=N, batch=B, procs=procs)
+    ctx = problems.make_ctx(prob)
+    ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
+    touts = [float(t) for t in prob["touts"][:3]]  # three Ida::solve calls: t = 0.1, 0.2, 0.3
+    for tout in touts:
+        status, tret = ens.solve(tout)
+        assert (status == 0).all()
+        assert np.array_equal(tret, np.full(B, tout))
+    out = {"prob": prob, "ctx": ctx, "ens": ens, "touts": touts, "tout": touts[-1], "yy": ens.yy(), "yp": ens.yp(),
+           "counters": ens.counters(), "hused": ens.real("hused")}
+    yield out
+    ens.close()
+
+
+def sub_problem(prob, ids):
+    return {k: (v[ids] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == B else v) for k, v in prob.items()}
+
+
+def test_sampled_systems_match_the_oracle_bit_for_bit(full):
+    sub = sub_problem(full["prob"], SAMPLE)
+    ref = O.run_ensemble("linear_dense", N, sub["yy0"], sub["yp0"], sub["rtol"], sub["atol"], full["touts"],
+                         A=sub["A"], B=sub["B"], c=sub["c"], nthreads=len(SAMPLE))
+    assert (ref["status"] == 0).all()
+    for k in CNT:
+        assert np.array_equal(full["counters"][k][SAMPLE], ref["counters"][k]), k
+    assert np.array_equal(full["counters"]["kused"][SAMPLE], ref["kused"])
+    assert np.array_equal(full["hused"][SAMPLE], ref["hused"])
+    assert np.array_equal(full["yy"][SAMPLE], ref["yy"][-1])
+    assert np.array_equal(full["yp"][SAMPLE], ref["yp"][-1])
+
+
+def test_result_does_not_depend_on_the_position_in_the_batch(full):
+    import idahip
+    from idahip import problems
+    ids = np.arange(1500, 1500 + 48)
+    sub = sub_problem(full["prob"], ids)
+    ctx = problems.make_ctx(sub)
+    ens = idahip.Ensemble(ctx, sub["yy0"], sub["yp0"])
+    for tout in full["touts"]:
+        status, _ = ens.solve(tout)
+        assert (status == 0).all()
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], full["counters"][k][ids]), k
+    assert np.array_equal(ens.yy(), full["yy"][ids])
+    assert np.array_equal(ens.yp(), full["yp"][ids])
+    assert np.array_equal(ens.real("hused"), full["hused"][ids])
+    ens.close()
+
+
+def test_full_batch_lu_factors_and_solves(full):
+    """idahip_nls_lsetup on all 4096 systems at once (J = B + cj A), then P J = L U and J x = b on sampled systems."""
+    import idahip
+    ctx, prob = full["ctx"], full["prob"]
+    cj = 37.5
+    rc, info = ctx.nls_lsetup(full["tout"], cj)
+    assert rc == 0 and not info.any()
+    rng = np.random.default_rng(5)
+    for s in SAMPLE[::3]:
+        lu, piv = ctx.download_lu(int(s))
+        J = (prob["B"][s] + cj * prob["A"][s]).T                  # stored [col][row] -> logical [row][col]
+        info_o, lu_o, piv_o = O.getrf(J)
+        assert info_o == 0
+        assert np.array_equal(piv, piv_o)
+        assert np.array_equal(lu, lu_o)
+        L = np.tril(lu, -1) + np.eye(N)
+        U = np.triu(lu)
+        PJ = J.copy()
+        for k in range(N):                                         # the reference's row interchanges, dense.rs:125-131
+            l = int(piv[k])
+            if l != k:
+                PJ[[k, l]] = PJ[[l, k]]
+        assert np.abs(L @ U - PJ).max() <= 1e-11 * np.abs(J).max() * N
+        b = rng.standard_normal(N)
+        x = O.getrs(lu, piv, b)
+        assert np.abs(J @ x - b).max() <= 1e-11 * N * (np.abs(J) @ np.abs(x)).max()  # backward-stable solve
