@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Development tool: device time of the LU with phases disabled (IDAHIP_LU_DBG), through the copy-free nls_lsetup path."""
+"""Development tool: device time of one batched Jacobian + LU (idahip_nls_lsetup, the copy-free path the stepper uses) on
+config-3 matrices. usage: [LU_VARIANT=v] python tools/panel_time.py [batch]; run two variants in one gpurun call for an A/B
+(box-to-box variation is a few per cent)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rust-ida_amd"))
