@@ -105,3 +105,47 @@ def test_full_batch_lu_factors_and_solves(full):
         b = rng.standard_normal(N)
         x = O.getrs(lu, piv, b)
         assert np.abs(J @ x - b).max() <= 1e-11 * N * (np.abs(J) @ np.abs(x)).max()  # backward-stable solve
+
+
+def test_config2_lorenz63_full_batch():
+    """Config 2 at its full size: 65,536 Lorenz systems (N = 3, the one-thread-per-system kernels), every system
+    bit-identical to the oracle -- state and counters -- at t = 0.1 .. 2.0."""
+    import idahip
+    from idahip import problems
+    p = problems.lorenz63(batch=65536)
+    touts = p["touts"][:20]
+    ctx = problems.make_ctx(p)
+    ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+    for t in touts:
+        status, _ = ens.solve(float(t))
+        assert (status == 0).all()
+    ref = O.run_ensemble("lorenz63", 3, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, params=p["params"],
+                         nthreads=min(64, os.cpu_count() or 1))
+    assert (ref["status"] == 0).all()
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(ens.yy(), ref["yy"][-1]) and np.array_equal(ens.yp(), ref["yp"][-1])
+    assert np.array_equal(ens.real("hused"), ref["hused"])
+    ens.close()
+
+
+def test_config4_heat1d_at_the_largest_supported_n():
+    """Config 4 (method-of-lines heat equation, tridiagonal Jacobian: the a_kj == 0 paths of the LU everywhere) at
+    N = 1024, the largest N of the blocked LU in this build (the survey's N = 4096 needs more than two rows per lane)."""
+    import idahip
+    from idahip import problems
+    p = problems.heat1d(n=1024, batch=4)
+    touts = p["touts"][:2]
+    ctx = problems.make_ctx(p)
+    ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+    for t in touts:
+        status, _ = ens.solve(float(t))
+        assert (status == 0).all()
+    ref = O.run_ensemble("heat1d", 1024, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, params=p["params"], nthreads=4)
+    assert (ref["status"] == 0).all()
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(ens.yy(), ref["yy"][-1]) and np.array_equal(ens.yp(), ref["yp"][-1])
+    ens.close()
