@@ -17,7 +17,8 @@ namespace idahip {
 constexpr int MXORDP1 = 6;      // src/constants.rs:6
 constexpr int TINY_N = 8;       // n <= TINY_N: one thread per system (whole Newton body in registers/L1)
 constexpr int LU_NB = 32;       // panel width of the blocked LU
-constexpr int LU_MAX_N = 1024;  // blocked LU: one panel row per thread, <= 1024 threads
+constexpr int LU_MAX_N = 1024;  // blocked LU, fast pipelines: at most two panel rows per lane of a 512-thread workgroup
+constexpr int LU_BIG_MAX_N = 4096;  // blocked LU with eight panel rows per lane for the leading super-panels
 constexpr int NSLOT = 8;
 
 struct Slot {

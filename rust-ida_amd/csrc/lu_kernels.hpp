@@ -484,6 +484,244 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------ panel, R rows per thread
+// lu_panel2_kernel for any number R of live rows per lane (rows t + i T of the live list): with narrow panels (NB = 8) and
+// R = 8 a 512-thread workgroup factors a panel of up to 4096 rows (R * NB * 2 = 128 VGPRs of panel entries). Used for the
+// leading super-panels of matrices with more than 1024 rows; the two-row kernel takes over below that.
+template <int NB, int R, int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, int lbase) {
+    constexpr int NW = MAXT / 64;
+    constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
+    static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
+    const int b = w.idx[blockIdx.x];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;
+    int* __restrict__ pos = w.pos + (long)b * n;
+    int* __restrict__ live = w.live + (long)b * n;
+    int* __restrict__ prow = w.prow + (long)b * n;
+    long long* __restrict__ piv = w.piv + (long)b * w.pstride;
+    double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
+
+    const int m = n - k0;
+    const int wd = m < NB ? m : NB;
+    const int T = blockDim.x;  // R * T >= m
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    __shared__ __align__(16) double s_row[2][NW][LDR];
+    __shared__ unsigned s_kh[2][16], s_kl[2][16];
+    __shared__ __align__(16) int s_p[2][16];
+    __shared__ unsigned long long s_zm[2][NW];
+    __shared__ int s_r[2][NW];
+    __shared__ int s_cnt[R][NW];
+
+    if (t < 32) {  // slots of waves that do not exist in this launch never win
+        (&s_kh[0][0])[t] = 0u;
+        (&s_kl[0][0])[t] = 0u;
+        (&s_p[0][0])[t] = 0x7fffffff;
+    }
+    bool valid[R], alive[R];
+    int r[R], mypos[R], ownk[R];
+    double a[R][NB];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int li = t + i * T;
+        valid[i] = li < m;
+        alive[i] = valid[i];
+        ownk[i] = -1;
+        r[i] = valid[i] ? live[li] : 0;
+        mypos[i] = valid[i] ? pos[r[i]] : 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[i][j] = (valid[i] && j < wd) ? A[(long)(k0 + j) * n + r[i]] : 0.0;
+    }
+    __syncthreads();
+
+    bool failed = false;
+    auto step = [&](const int k) -> bool {
+        const int kc = k0 + k;
+        const int par = k & 1;
+        // candidate key of a live row: the bit pattern of |a| with the always-clear sign bit set (0 = no candidate);
+        // ties go to the lowest position; NaN only wins at position kc (dense.rs:111-117 scan semantics)
+        unsigned kh[R], kl[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            kh[i] = 0u;
+            kl[i] = 0u;
+            if (alive[i]) {
+                const double v = fabs(a[i][0]);
+                kh[i] = (unsigned)__double2hiint(v) | 0x80000000u;
+                kl[i] = (unsigned)__double2loint(v);
+                if (v != v) {
+                    kh[i] = (mypos[i] == kc) ? 0xfff00000u : 0u;
+                    kl[i] = 0u;
+                }
+            }
+        }
+        // the best of the lane's own rows
+        int sel = 0;
+        unsigned bkh = kh[0], bkl = kl[0];
+        int bpos = mypos[0];
+        double a0 = a[0][0];
+#pragma unroll
+        for (int i = 1; i < R; ++i) {
+            const bool better = kh[i] > bkh || (kh[i] == bkh && (kl[i] > bkl || (kl[i] == bkl && mypos[i] < bpos)));
+            if (better) {
+                sel = i;
+                bkh = kh[i];
+                bkl = kl[i];
+                bpos = mypos[i];
+                a0 = a[i][0];
+            }
+        }
+        const double myrecip = 1.0 / a0;  // mult = a(k,k).recip() (dense.rs:134), off the critical path
+        const unsigned mh = wave_max_u32<false>(bkh);
+        const unsigned ml = wave_max_u32<false>(bkh == mh ? bkl : 0u);
+        const bool top = bkh != 0u && bkh == mh && bkl == ml;
+        const int pm = wave_min_i32f<false>(top ? bpos : 0x7fffffff);
+        const bool cand = top && bpos == pm;  // this wave's candidate row (one lane, or none)
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (cand && sel == i) {
+#pragma unroll
+                for (int j = 0; j < NB; j += 2) {
+                    double2 q;
+                    q.x = a[i][j];
+                    q.y = a[i][j + 1];
+                    *reinterpret_cast<double2*>(&s_row[par][wave][j]) = q;
+                }
+                s_r[par][wave] = r[i];
+            }
+        }
+        if (cand) s_row[par][wave][NB] = myrecip;
+        {   // zero mask of the candidate row (dense.rs:148): one entry per lane, one ballot
+            const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
+            const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
+            if (lane == 0) {
+                s_zm[par][wave] = zm;
+                s_kh[par][wave] = mh;  // 0 when the wave has no live row
+                s_kl[par][wave] = ml;
+                s_p[par][wave] = pm;
+            }
+        }
+        lds_barrier();
+        int bp, bw;
+        {
+            const int q = lane & 15;
+            const unsigned ch = s_kh[par][q], cl = s_kl[par][q];
+            const int cp = s_p[par][q];
+            const unsigned bh = wave_max_u32<true>(ch);
+            const unsigned bl = wave_max_u32<true>(ch == bh ? cl : 0u);
+            const int kmin = wave_min_i32f<true>((ch == bh && cl == bl) ? ((cp << 4) | q) : 0x7fffffff);
+            bp = kmin >> 4;
+            bw = kmin & 15;
+        }
+        const double pk = s_row[par][bw][0];
+        if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
+            if (t == 0) w.info[b] = kc + 1;
+            return false;
+        }
+        if (t == 0) piv[kc] = (long long)bp;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (alive[i] && mypos[i] == bp) {  // this row is the pivot
+                prow[kc] = r[i];
+                ownk[i] = k;
+                alive[i] = false;
+                mypos[i] = kc;
+            } else if (alive[i] && mypos[i] == kc) {
+                mypos[i] = bp;  // the row that sat at position k moves to the pivot's old position
+            }
+        }
+        // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
+        if (wave == 0 && lane < NB && k + lane < wd)
+            A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
+        const double recip = s_row[par][bw][NB];
+        double aik[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            aik[i] = a[i][0] * recip;
+            if (alive[i]) A[(long)kc * n + r[i]] = aik[i];  // the multiplier is final (coalesced column store)
+        }
+        const unsigned long long zmv = s_zm[par][bw];
+        const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
+        // the arithmetic runs on every lane (rows that are not live compute values nobody reads)
+        if (zm == 0ull) {
+#pragma unroll
+            for (int jc = 0; jc < NB; jc += 8) {
+                double u[8];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
+                    u[j] = q.x;
+                    u[j + 1] = q.y;
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (jc + j >= 1) a[i][jc + j - 1] = a[i][jc + j] - u[j] * aik[i];  // dense.rs:151, rotated one column
+            }
+        } else {
+#pragma unroll
+            for (int j = 1; j < NB; ++j) {
+                const double uj = s_row[par][bw][j];
+#pragma unroll
+                for (int i = 0; i < R; ++i) a[i][j - 1] = ((zm >> j) & 1ull) ? a[i][j] : a[i][j] - uj * aik[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) a[i][NB - 1] = 0.0;
+        return true;
+    };
+#pragma unroll 1
+    for (int k = 0; k < wd; ++k)
+        if (!step(k)) { failed = true; break; }
+    if (failed) return;
+
+    // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (valid[i]) pos[r[i]] = mypos[i];
+    __syncthreads();  // the multipliers stored above are visible to the whole workgroup
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (ownk[i] >= 0) {
+            const int kq = lbase + ownk[i];  // index of this pivot row inside the enclosing super-panel
+            const double* __restrict__ src = A + (long)(k0 - lbase) * n + r[i];
+            for (int j0 = 0; j0 < kq; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (j0 + u < kq) ? src[(long)(j0 + u) * n] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < kq) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
+            }
+        }
+    }
+    // live list: the surviving rows of set 0 in thread order, then those of set 1 (the list stays sorted)
+    unsigned long long bal[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        bal[i] = __ballot(alive[i]);
+        if (lane == 0) s_cnt[i][wave] = __popcll(bal[i]);
+    }
+    __syncthreads();
+    const int nwaves = T >> 6;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        int mine = base;
+        for (int q = 0; q < nwaves; ++q) {
+            const int c = s_cnt[i][q];
+            if (q < wave) mine += c;
+            base += c;
+        }
+        if (alive[i]) live[mine + __popcll(bal[i] & ((1ull << lane) - 1ull))] = r[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ trailing (fused)
 // One workgroup per (matrix, block of 64 trailing columns): gathers the NB pivot rows of the block, solves
 // U12 = L11^-1 A12 in LDS (one wave, one column per lane, L11 staged in LDS), writes the final U rows back,
@@ -492,8 +730,8 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, in
 //   and 4 U entries from LDS (conflict-free b64 reads) for 16 updates -> VALU-bound, ~100 VGPRs, 3 workgroups per CU.
 // No Ubuf round trip, no per-lane operand broadcast; the matrix is touched in coalesced column segments only
 // (the pivot-row gather/scatter is the one strided access: NB x 64 elements per workgroup).
-template <int NB>
-__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit) {
+template <int NB, int MAXROWS>
+__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit, int l11off) {
     // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so the column blocks of one matrix are
     // given ids with equal (id & 7) and adjacent (id >> 3): they run on one XCD at about the same time and share the
     // multiplier panel L21 (read by every column block) through that XCD's L2 instead of re-reading it from HBM.
@@ -506,7 +744,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     double* __restrict__ A = w.mats + (long)b * w.mstride;
     const int* __restrict__ live = w.live + (long)b * n;
     const int* __restrict__ prow = w.prow + (long)b * n + k0;
-    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
+    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE + l11off;  // diagonal block of this (sub-)panel
 
     const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
     const int cb0 = k0 + NB + cbi * 64;
@@ -517,7 +755,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     constexpr int LD = 66;  // padded row (doubles): rows stay 16-byte aligned, column reads conflict-free
     __shared__ __align__(16) double Us[NB][LD];
     __shared__ __align__(16) double Ls[2][NB][LD];
-    __shared__ unsigned short s_live[LU_MAX_N];  // n <= 1024 < 65536
+    __shared__ unsigned short s_live[MAXROWS];  // row indices < 65536
     __shared__ int s_anyzero;
 
     for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
@@ -894,8 +1132,9 @@ __global__ __launch_bounds__(256, 3) void lu_trail64_kernel(LuWs w, int k0, int 
 // stages the multipliers of ITS rows in its own 4 KB of LDS, so the update loop has no workgroup barrier at all -- waves
 // only meet in the U12 prologue. Per lane a 4 x 4 register tile (rows a + 4i of the strip, columns q + 16j); L and U are
 // stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU ops.
-__global__ __launch_bounds__(256, 3) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
-    constexpr int NB = 64, KC = 32, MAXROWS = LU_MAX_N;
+template <int MAXROWS>
+__global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
+    constexpr int NB = 64, KC = 32;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
     if (mi >= nsys) return;
@@ -1193,7 +1432,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                            pstride, perm, c->lu_info);
         return 0;
     }
-    if (n > LU_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_MAX_N, n);
+    if (n > LU_BIG_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_BIG_MAX_N, n);
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info;
@@ -1212,24 +1451,40 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    const bool two_rows = c->lu_variant >= 3;
-    if (c->lu_variant >= 2) {
+    const bool two_rows = c->lu_variant >= 3 || n > LU_MAX_N;
+    if (c->lu_variant >= 2 || n > LU_MAX_N) {
         // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
         // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
         // kernel, the rest of the matrix sees both at once in the rank-64 kernel.
         w.l11ld = 64;
         for (int k0 = 0; k0 < n; k0 += 64) {
+            if (n - k0 > LU_MAX_N) {
+                // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
+                // update of the rest of the super-panel; the rank-64 trailing kernel below is the same
+                constexpr int NBS = 8;
+                const int cend = (k0 + 64 < n) ? k0 + 64 : n;
+                const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
+                for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
+                    hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
+                    if (k0 + lb + NBS < cend)
+                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                                           cend, lb * 65);
+                }
+            } else {
             if (two_rows) panel2(k0, 0); else panel(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
-                hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend);
+                hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0);
                 if (two_rows) panel2(k0 + NB, NB); else panel(k0 + NB, NB);
+            }
             }
             const int ntrail = n - k0 - 64;
             if (ntrail > 0) {
                 const int ncb = (ntrail + 63) / 64;
-                if (c->lu_variant == 4)
-                    hipLaunchKernelGGL(lu_trail64w_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                if (n > LU_MAX_N)
+                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                else if (c->lu_variant == 4)
+                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 else
                     hipLaunchKernelGGL(lu_trail64_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             }
@@ -1243,7 +1498,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int ntrail = n - k0 - NB;
         if (ntrail > 0) {
             const int ncb = (ntrail + 63) / 64;
-            hipLaunchKernelGGL(lu_trail_kernel<NB>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n);
+            hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n, 0);
         }
     }
     const int cpb = 32;

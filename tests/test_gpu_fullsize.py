@@ -130,19 +130,22 @@ def test_config2_lorenz63_full_batch():
     ens.close()
 
 
-def test_config4_heat1d_at_the_largest_supported_n():
+@pytest.mark.parametrize("n,batch,ntout", [(1024, 4, 2), (4096, 256, 1)])
+def test_config4_heat1d(n, batch, ntout):
     """Config 4 (method-of-lines heat equation, tridiagonal Jacobian: the a_kj == 0 paths of the LU everywhere) at
-    N = 1024, the largest N of the blocked LU in this build (the survey's N = 4096 needs more than two rows per lane)."""
+    N = 1024 (largest N of the two-rows-per-lane panels) and at its full size, N = 4096 with 256 systems (eight rows
+    per lane in the leading super-panels)."""
     import idahip
     from idahip import problems
-    p = problems.heat1d(n=1024, batch=4)
-    touts = p["touts"][:2]
+    p = problems.heat1d(n=n, batch=batch)
+    touts = p["touts"][:ntout]
     ctx = problems.make_ctx(p)
     ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
     for t in touts:
         status, _ = ens.solve(float(t))
         assert (status == 0).all()
-    ref = O.run_ensemble("heat1d", 1024, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, params=p["params"], nthreads=4)
+    ref = O.run_ensemble("heat1d", n, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, params=p["params"],
+                         nthreads=min(batch, 64, os.cpu_count() or 1))
     assert (ref["status"] == 0).all()
     c = ens.counters()
     for k in CNT:

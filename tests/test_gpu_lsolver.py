@@ -96,6 +96,30 @@ def test_lu_and_solve_random_bit_exact(n):
     assert np.array_equal(x, x_o)
 
 
+@pytest.mark.parametrize("n", [1025, 1100, 1600, 2048])
+def test_lu_beyond_1024_rows(n):
+    """More than 1024 rows: the leading super-panels run with eight 8-column panels and eight rows per lane (whatever
+    the LU variant), the rest with the selected pipeline."""
+    if LU_VARIANT not in (0, 4):
+        pytest.skip("the large-n pipeline does not depend on the variant; two of them are enough")
+    rng = np.random.default_rng(n)
+    B = 2
+    mats = rng.standard_normal((B, n, n))
+    mats[1][np.abs(mats[1]) < 1.0] = 0.0           # many exact zeros: the a_kj == 0 paths
+    mats[1] += np.diag(np.full(n, 5.0))
+    rhs = rng.standard_normal((B, n))
+    info_o, lu_o, piv_o = oracle_lu(mats)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(mats)
+    assert rc == 0 and np.array_equal(info, info_o)
+    assert np.array_equal(piv, piv_o)
+    assert np.array_equal(lu, lu_o)
+    dB = ctx.dev_array(rhs)
+    dX = ctx.dev_empty(rhs.nbytes)
+    ctx.ls_solve(dA, dP, dX, dB)
+    x_o = np.array([O.getrs(lu_o[s], piv_o[s], rhs[s]) for s in range(B)])
+    assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
+
+
 def test_pivot_ties_resolve_like_the_reference_scan():
     n = 40
     rng = np.random.default_rng(7)
