@@ -39,13 +39,15 @@ def algorithmic_bytes(n):
         "newton_iter": 8 * n * n + 40 * n + 8,   # getrs 8N^2+24N, + neg/scale/axpy/wrms vectors 16N+8
         "sys": 16 * n * n + 40 * n,              # residual of the linear dense DAE
         "jac": 24 * n * n,                       # J = B + cj A
+        "sys_jac": 24 * n * n + 40 * n,          # residual and J = B + cj A in one pass over A and B
         "lu": 16 * n * n + 8 * n,                # getrf: read + write the matrix once, pivots
     }
 
 
 KERNEL_OF_CLASS = {
     "lu": "batched getrf = the lu_panel2 / lu_trail / lu_trail64 / lu_finalize kernel launches of one idahip_nls_lsetup call",
-    "sys": "linear_sys_kernel", "newton_iter": "newton_iter_kernel", "jac": "linear_jac_kernel",
+    "sys": "linear_sys_kernel<2, false>", "newton_iter": "newton_iter_kernel", "jac": "linear_jac_kernel",
+    "sys_jac": "linear_sys_kernel<2, true>",
 }
 
 
@@ -58,13 +60,14 @@ def profiled_traffic(cls):
         s = json.load(open(path))
     except Exception:
         return None
-    names = {"lu": ("lu_",), "sys": ("linear_sys_kernel",),
+    names = {"lu": ("lu_",), "sys": ("linear_sys_kernel<2, false>", "linear_sys_kernel<1, false>"),
+             "sys_jac": ("linear_sys_kernel<2, true>", "linear_sys_kernel<1, true>"),
              "newton_iter": ("newton_iter_kernel",), "jac": ("linear_jac_kernel",)}[cls]
     tot = 0.0
     for k, v in s["kernels"].items():
         if k.startswith(names) and "hbm_read_GB_total" in v:
             tot += v["hbm_read_GB_total"] + v["hbm_write_GB_total"]
-    systems = s["bench"]["kernel_classes_rank0"][cls]["systems"]
+    systems = s["bench"]["kernel_classes_rank0"].get(cls, {}).get("systems", 0)
     return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
 
 
@@ -258,11 +261,11 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(args.n)
-        dom = max(("newton_iter", "sys", "jac", "lu"), key=lambda k: tim[k]["ms"])
+        dom = max(("newton_iter", "sys", "sys_jac", "jac", "lu"), key=lambda k: tim[k]["ms"])
         d = tim[dom]
         achieved = (ab[dom] * d["systems"]) / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         classes = {}
-        for k in ("newton_iter", "sys", "jac", "lu", "vector"):
+        for k in ("newton_iter", "sys", "sys_jac", "jac", "lu", "vector"):
             v = tim[k]
             ent = {"ms": round(v["ms"], 3), "calls": v["launches"], "systems": v["systems"]}
             if k in ab and v["ms"] > 0:

@@ -88,6 +88,13 @@ int idahip_ls_solve(idahip_ctx* ctx, const double* dLU, const int64_t* dPiv, dou
 /* NormRms::norm_wrms (src/norm_rms.rs:31-38): hOut[s] = sqrt(sum_i (x_i w_i)^2 / n), summed left to right */
 int idahip_wrms(idahip_ctx* ctx, const double* dX, const double* dW, double* hOut, const int32_t* hIdx, int nsys);
 
+/* IdaNLProblem::sys immediately followed by IdaNLProblem::setup for the same systems -- the order Newton::solve runs them
+ * in when call_lsetup is set (crates/nonlinear/src/newton.rs:73-96; src/ida_nls.rs:118-188). Same results as
+ * idahip_nls_sys + idahip_nls_lsetup; for the linear dense problem the residual pass also forms J = B + cj*A, so A and B are
+ * read once instead of twice. hInfo / return value as idahip_nls_lsetup. */
+int idahip_nls_sys_setup(idahip_ctx* ctx, const double* hTn, const double* hCj, int reset_ee, int32_t* hInfo,
+                         const int32_t* hIdx, int nsys);
+
 /* ---- NLProblem trait as implemented by IdaNLProblem (src/ida_nls.rs:118-266), on the ctx-resident state ----
  * sys    = idaNlsResidual (:118-153): yy = yypredict + ycor; yp = yppredict + cj*ycor; delta = savres = F(tn,yy,yp).
  *          ycor is the accumulated correction `ee` (Newton's y); reset_ee != 0 first sets ee = 0 (Newton's y <- y0 = 0,
@@ -138,7 +145,8 @@ int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
  * ctx stream, and launch counters per kernel class ---- */
 typedef enum {
     IDAHIP_K_NEWTON_ITER = 0, IDAHIP_K_SYS = 1, IDAHIP_K_JAC = 2, IDAHIP_K_LU = 3, IDAHIP_K_VECTOR = 4, IDAHIP_K_SOLVE = 5,
-    IDAHIP_K_COUNT = 6
+    IDAHIP_K_SYS_JAC = 6, /* fused residual + Jacobian pass of idahip_nls_sys_setup */
+    IDAHIP_K_COUNT = 7
 } idahip_kclass;
 int idahip_timing_enable(idahip_ctx* ctx, int on);
 /* accumulated device milliseconds and launch count of a kernel class since the last reset */

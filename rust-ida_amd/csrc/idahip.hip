@@ -339,97 +339,81 @@ int idahip_wrms(idahip_ctx* c, const double* dX, const double* dW, double* hOut,
 }
 
 // ------------------------------------------------------------------------------------------------ NLProblem
-int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys) {
-    int rc = check_list(c, hIdx, nsys);
-    if (rc) return rc;
-    if (!hTn || !hCj) return fail(c, -2, "null argument");
-    if (nsys == 0) return 0;
+namespace {
+
+// residual kernels of IdaNLProblem::sys; jac_out != nullptr (linear dense, column-major work matrix only) also forms J
+int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out) {
     const int n = c->n;
-    ArgPack ap;
-    if ((rc = ap.begin(c))) return rc;
-    SysArgs a;
-    a.idx = ap.in(hIdx, nsys);
-    a.tn = ap.in(hTn, nsys);
-    a.cj = ap.in(hCj, nsys);
-    if ((rc = ap.upload())) return rc;
-    a.yypredict = c->yypredict; a.yppredict = c->yppredict; a.yy = c->yy; a.yp = c->yp; a.ee = c->ee; a.delta = c->delta;
-    a.savres = c->savres; a.n = n; a.reset_ee = reset_ee;
-    {
-        KTimer kt(c, IDAHIP_K_SYS, nsys);
-        switch (c->kind) {
-            case IDAHIP_ROBERTS:
-                hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)nullptr, 0, nsys);
-                break;
-            case IDAHIP_LORENZ63:
-                hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)c->params, 3, nsys);
-                break;
-            case IDAHIP_LINEAR_DENSE:
-                if (n % 2 == 0)
-                    hipLaunchKernelGGL(linear_sys_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, a, (const double*)c->A,
-                                       (const double*)c->B, (const double*)c->C);
-                else
-                    hipLaunchKernelGGL(linear_sys_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, a, (const double*)c->A,
-                                       (const double*)c->B, (const double*)c->C);
-                break;
-            case IDAHIP_HEAT1D:
-                hipLaunchKernelGGL(heat_sys_kernel, dim3(nsys), dim3(256), sizeof(double) * n, c->stream, a, (const double*)c->params);
-                break;
+    switch (c->kind) {
+        case IDAHIP_ROBERTS:
+            hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)nullptr, 0, nsys);
+            break;
+        case IDAHIP_LORENZ63:
+            hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)c->params, 3, nsys);
+            break;
+        case IDAHIP_LINEAR_DENSE: {
+            const size_t shm = 2 * sizeof(double) * n;
+            const double *A = c->A, *B = c->B, *C = c->C;
+            if (jac_out) {
+                if (n % 2 == 0) hipLaunchKernelGGL((linear_sys_kernel<2, true>), dim3(nsys), dim3(256), shm, c->stream, a, A, B, C, jac_out);
+                else hipLaunchKernelGGL((linear_sys_kernel<1, true>), dim3(nsys), dim3(256), shm, c->stream, a, A, B, C, jac_out);
+            } else {
+                if (n % 2 == 0) hipLaunchKernelGGL((linear_sys_kernel<2, false>), dim3(nsys), dim3(256), shm, c->stream, a, A, B, C, (double*)nullptr);
+                else hipLaunchKernelGGL((linear_sys_kernel<1, false>), dim3(nsys), dim3(256), shm, c->stream, a, A, B, C, (double*)nullptr);
+            }
+            break;
         }
-        if ((rc = post_launch(c, "nls_sys"))) return rc;
+        case IDAHIP_HEAT1D:
+            hipLaunchKernelGGL(heat_sys_kernel, dim3(nsys), dim3(256), sizeof(double) * n, c->stream, a, (const double*)c->params);
+            break;
     }
-    return ap.finish_async();
+    return post_launch(c, "nls_sys");
 }
 
-int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys) {
-    int rc = check_list(c, hIdx, nsys);
-    if (rc) return rc;
-    if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
-    if (nsys == 0) return 0;
+// Jacobian kernels of IdaNLProblem::setup (jac at the current yy, yp, cj) into the LU work matrix
+int launch_jac(idahip_ctx* c, double* work, bool rm, const int* d_idx, const double* d_cj, int nsys) {
     const int n = c->n;
     const long nn = (long)n * n;
-    ArgPack ap;
-    if ((rc = ap.begin(c))) return rc;
-    const int* d_idx = ap.in(hIdx, nsys);
-    const double* d_cj = ap.in(hCj, nsys);
-    if ((rc = ap.upload())) return rc;
-    double* work = (n <= TINY_N) ? c->lu : c->jw;
-    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);  // Jacobian written row-major for the factorisation
-    {
-        KTimer kt(c, IDAHIP_K_JAC, nsys);
-        switch (c->kind) {
-            case IDAHIP_ROBERTS:
-                hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
-                                   (const double*)nullptr, 0, d_idx, d_cj, nsys);
-                break;
-            case IDAHIP_LORENZ63:
-                hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
-                                   (const double*)c->params, 3, d_idx, d_cj, nsys);
-                break;
-            case IDAHIP_LINEAR_DENSE: {
-                if (rm) {
-                    const int nb64 = (n + 63) / 64;
-                    hipLaunchKernelGGL(linear_jac_rm_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, work, (const double*)c->A,
-                                       (const double*)c->B, n, d_idx, d_cj);
-                } else {
-                    int chunks = 1;
-                    while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
-                    hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A,
-                                       (const double*)c->B, nn, d_idx, d_cj, chunks);
-                }
-                break;
-            }
-            case IDAHIP_HEAT1D: {
+    switch (c->kind) {
+        case IDAHIP_ROBERTS:
+            hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
+                               (const double*)nullptr, 0, d_idx, d_cj, nsys);
+            break;
+        case IDAHIP_LORENZ63:
+            hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_LORENZ63>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
+                               (const double*)c->params, 3, d_idx, d_cj, nsys);
+            break;
+        case IDAHIP_LINEAR_DENSE: {
+            if (rm) {
+                const int nb64 = (n + 63) / 64;
+                hipLaunchKernelGGL(linear_jac_rm_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, work, (const double*)c->A,
+                                   (const double*)c->B, n, d_idx, d_cj);
+            } else {
                 int chunks = 1;
-                while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
-                if (rm)
-                    hipLaunchKernelGGL(heat_jac_rm_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
-                else
-                    hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
-                break;
+                while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
+                hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A,
+                                   (const double*)c->B, nn, d_idx, d_cj, chunks);
             }
+            break;
         }
-        if ((rc = post_launch(c, "jac"))) return rc;
+        case IDAHIP_HEAT1D: {
+            int chunks = 1;
+            while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
+            if (rm)
+                hipLaunchKernelGGL(heat_jac_rm_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+            else
+                hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+            break;
+        }
     }
+    return post_launch(c, "jac");
+}
+
+// batched getrf of the work matrices into ctx->lu / piv / perm, then the per-system info of the listed systems
+int factor_and_report(idahip_ctx* c, double* work, bool rm, const int* d_idx, const int32_t* hIdx, int nsys, int32_t* hInfo) {
+    const int n = c->n;
+    const long nn = (long)n * n;
+    int rc;
     {
         KTimer kt(c, IDAHIP_K_LU, nsys);
         rc = rm ? rm_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys)
@@ -446,6 +430,83 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
         any |= hInfo[s] != 0;
     }
     return any ? 1 : 0;
+}
+
+void fill_sys_args(idahip_ctx* c, SysArgs& a, int reset_ee) {
+    a.yypredict = c->yypredict; a.yppredict = c->yppredict; a.yy = c->yy; a.yp = c->yp; a.ee = c->ee; a.delta = c->delta;
+    a.savres = c->savres; a.n = c->n; a.reset_ee = reset_ee;
+}
+
+}  // namespace
+
+int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hTn || !hCj) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    SysArgs a;
+    a.idx = ap.in(hIdx, nsys);
+    a.tn = ap.in(hTn, nsys);
+    a.cj = ap.in(hCj, nsys);
+    if ((rc = ap.upload())) return rc;
+    fill_sys_args(c, a, reset_ee);
+    {
+        KTimer kt(c, IDAHIP_K_SYS, nsys);
+        if ((rc = launch_sys(c, a, nsys, nullptr))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const double* d_cj = ap.in(hCj, nsys);
+    if ((rc = ap.upload())) return rc;
+    double* work = (n <= TINY_N) ? c->lu : c->jw;
+    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);  // Jacobian written row-major for the factorisation
+    {
+        KTimer kt(c, IDAHIP_K_JAC, nsys);
+        if ((rc = launch_jac(c, work, rm, d_idx, d_cj, nsys))) return rc;
+    }
+    return factor_and_report(c, work, rm, d_idx, hIdx, nsys, hInfo);
+}
+
+int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, int32_t* hInfo, const int32_t* hIdx,
+                         int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    SysArgs a;
+    a.idx = ap.in(hIdx, nsys);
+    a.tn = ap.in(hTn, nsys);
+    a.cj = ap.in(hCj, nsys);
+    if ((rc = ap.upload())) return rc;
+    fill_sys_args(c, a, reset_ee);
+    double* work = (n <= TINY_N) ? c->lu : c->jw;
+    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);
+    // the linear dense residual sweeps A and B anyway: J = B + cj*A falls out of the same pass
+    const bool fused = c->kind == IDAHIP_LINEAR_DENSE && n > TINY_N && !rm;
+    {
+        KTimer kt(c, fused ? IDAHIP_K_SYS_JAC : IDAHIP_K_SYS, nsys);
+        if ((rc = launch_sys(c, a, nsys, fused ? work : nullptr))) return rc;
+    }
+    if (!fused) {
+        KTimer kt(c, IDAHIP_K_JAC, nsys);
+        if ((rc = launch_jac(c, work, rm, a.idx, a.cj, nsys))) return rc;
+    }
+    return factor_and_report(c, work, rm, a.idx, hIdx, nsys, hInfo);
 }
 
 int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys) {

@@ -97,9 +97,11 @@ __global__ void tiny_jac_kernel(double* mats, const double* __restrict__ yy, con
 
 // ------------------------------------------------------------------------------------------------ linear dense
 // One workgroup (256 threads) per system; thread t owns rows {VEC*t + v + VEC*256*pass}; sweeps columns j ascending.
-template <int VEC>
+// WITH_JAC: the sweep also writes the Newton matrix J = B + cj*A (mul, then add -- as linear_jac_kernel) to Jout, column-
+// major: when the reference's Newton::solve calls setup right after sys (call_lsetup), A and B are read once for both.
+template <int VEC, bool WITH_JAC>
 __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double* __restrict__ A, const double* __restrict__ Bm,
-                                                         const double* __restrict__ C) {
+                                                         const double* __restrict__ C, double* __restrict__ Jout) {
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
     double* syy = sm;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
     __syncthreads();
     const double* __restrict__ Ab = A + (long)b * n * n;
     const double* __restrict__ Bb = Bm + (long)b * n * n;
+    double* __restrict__ Jb = WITH_JAC ? Jout + (long)b * n * n : nullptr;
     for (int i = VEC * t; i < n; i += VEC * 256) {
         double ra[VEC], rb[VEC];
 #pragma unroll
@@ -145,6 +148,20 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
                     bv[u][0] = *pb;
                 }
             }
+            if constexpr (WITH_JAC) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    double* pj = Jb + (long)(j + u) * n + i;
+                    if constexpr (VEC == 2) {
+                        double2 o;
+                        o.x = bv[u][0] + cj * av[u][0];
+                        o.y = bv[u][1] + cj * av[u][1];
+                        *reinterpret_cast<double2*>(pj) = o;
+                    } else {
+                        *pj = bv[u][0] + cj * av[u][0];
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const double ypj = syp[j + u], yyj = syy[j + u];
@@ -159,8 +176,10 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 if (i + v < n) {
-                    ra[v] = ra[v] + Ab[(long)j * n + i + v] * syp[j];
-                    rb[v] = rb[v] + Bb[(long)j * n + i + v] * syy[j];
+                    const double ae = Ab[(long)j * n + i + v], be = Bb[(long)j * n + i + v];
+                    if constexpr (WITH_JAC) Jb[(long)j * n + i + v] = be + cj * ae;
+                    ra[v] = ra[v] + ae * syp[j];
+                    rb[v] = rb[v] + be * syy[j];
                 }
             }
         }

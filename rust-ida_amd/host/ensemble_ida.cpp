@@ -391,22 +391,27 @@ int flush_solutions(idaens* e, SolList& sl) {
 // `act`: systems taking a step attempt this round, with s.call_lsetup decided. Sets s.nls_ret.
 int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
     std::vector<Sys>& S = e->sys;
-    std::vector<int32_t> R(act), I, C, L;
+    std::vector<int32_t> R(act), I, C, L, P;
     std::vector<uint8_t> jbad(e->batch, 0);
     std::vector<double> tn, cj, sc, nrm;
     std::vector<int32_t> info;
     while (!R.empty() || !I.empty()) {
         if (!R.empty()) {
-            tn.clear(); cj.clear();
-            for (int b : R) { tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
-            ENS_CALL(e, idahip_nls_sys(e->ctx, tn.data(), cj.data(), 1, R.data(), (int)R.size()));  // sys(y0), y <- y0 = 0
+            // sys(y0), y <- y0 = 0 (newton.rs:73); the systems whose Newton solve then calls setup (call_lsetup) get both
+            // in one device call, the others sys alone
+            L.clear(); P.clear();
+            for (int b : R) (S[b].call_lsetup ? L : P).push_back(b);
+            if (!P.empty()) {
+                tn.clear(); cj.clear();
+                for (int b : P) { tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
+                ENS_CALL(e, idahip_nls_sys(e->ctx, tn.data(), cj.data(), 1, P.data(), (int)P.size()));
+            }
             for (int b : R) S[b].nre += 1;
-            L.clear(); tn.clear(); cj.clear();
-            for (int b : R)
-                if (S[b].call_lsetup) { L.push_back(b); tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
             if (!L.empty()) {
+                tn.clear(); cj.clear();
+                for (int b : L) { tn.push_back(S[b].tn); cj.push_back(S[b].cj); }
                 info.assign(L.size(), 0);
-                ENS_CALL(e, idahip_nls_lsetup(e->ctx, tn.data(), cj.data(), info.data(), L.data(), (int)L.size()));
+                ENS_CALL(e, idahip_nls_sys_setup(e->ctx, tn.data(), cj.data(), 1, info.data(), L.data(), (int)L.size()));
                 for (size_t q = 0; q < L.size(); ++q) {
                     Sys& s = S[L[q]];
                     s.nsetups += 1;  // idaNlsLSetup (ida_nls.rs:168)

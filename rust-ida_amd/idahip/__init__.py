@@ -21,15 +21,15 @@ i64p = C.POINTER(C.c_int64)
 ROBERTS, LORENZ63, LINEAR_DENSE, HEAT1D = 0, 1, 2, 3
 KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, "heat1d": HEAT1D}
 F_YY, F_YP, F_YYPREDICT, F_YPPREDICT, F_EWT, F_EE, F_DELTA, F_SAVRES, F_PHI0 = range(9)
-K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE = range(6)
-K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve"]
+K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE, K_SYS_JAC = range(7)
+K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac"]
 
 # symbols declared in include/ida_hip.h / include/ida_ensemble.h (checked by tests/test_abi_symbols.py)
 HIP_SYMBOLS = [
     "idahip_create", "idahip_destroy", "idahip_last_error", "idahip_sync", "idahip_n", "idahip_batch", "idahip_set_tolerances",
     "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_upload", "idahip_download", "idahip_download_lu",
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
-    "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
+    "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant",
 ]
@@ -89,6 +89,7 @@ def load():
     H.idahip_wrms.argtypes = [vp, vp, vp, dp, i32p, ci]
     H.idahip_nls_sys.argtypes = [vp, dp, dp, ci, i32p, ci]
     H.idahip_nls_lsetup.argtypes = [vp, dp, dp, i32p, i32p, ci]
+    H.idahip_nls_sys_setup.argtypes = [vp, dp, dp, ci, i32p, i32p, ci]
     H.idahip_newton_iter.argtypes = [vp, dp, dp, i32p, ci]
     H.idahip_init_first.argtypes = [vp, dp, dp, i32p, ci]
     H.idahip_scale_phi1.argtypes = [vp, dp, i32p, ci]
@@ -242,6 +243,15 @@ class Ctx:
         tn, cj = _f64(np.broadcast_to(tn, idx.shape)), _f64(np.broadcast_to(cj, idx.shape))
         info = np.zeros(idx.size, dtype=np.int32)
         rc = self._chk(self.H.idahip_nls_lsetup(self.h, _p(tn), _p(cj), _p(info, i32p), _p(idx, i32p), idx.size), "nls_lsetup")
+        return rc, info
+
+    def nls_sys_setup(self, tn, cj, reset_ee=True, idx=None):
+        """sys immediately followed by setup (one pass over A and B for the linear dense problem)."""
+        idx = self.all_idx() if idx is None else _i32(idx)
+        tn, cj = _f64(np.broadcast_to(tn, idx.shape)), _f64(np.broadcast_to(cj, idx.shape))
+        info = np.zeros(idx.size, dtype=np.int32)
+        rc = self._chk(self.H.idahip_nls_sys_setup(self.h, _p(tn), _p(cj), int(bool(reset_ee)), _p(info, i32p), _p(idx, i32p), idx.size),
+                       "nls_sys_setup")
         return rc, info
 
     def newton_iter(self, scale, idx=None):

@@ -164,3 +164,38 @@ def test_mxstep_is_reported_per_system():
     ens.set_max_num_steps(5)
     st, tret = ens.solve(1.0)
     assert (st == -1).all() and (ens.counter("nst") == 5).all()  # IDA_TOO_MUCH_WORK after mxstep steps
+
+
+@pytest.mark.parametrize("kind,n,batch", [("linear_dense", 64, 5), ("linear_dense", 33, 3), ("heat1d", 40, 3), ("lorenz63", 3, 7)])
+def test_sys_setup_in_one_call_equals_sys_then_lsetup(kind, n, batch):
+    """idahip_nls_sys_setup (sys + setup in one device call; for the linear dense problem J = B + cj A falls out of the
+    residual pass) leaves the same residual, factors, pivots and state as idahip_nls_sys followed by idahip_nls_lsetup."""
+    import idahip
+    from idahip import problems
+    p = {"linear_dense": lambda: problems.linear_dense(n=n, batch=batch), "heat1d": lambda: problems.heat1d(n=n, batch=batch),
+         "lorenz63": lambda: problems.lorenz63(batch=batch)}[kind]()
+    rng = np.random.default_rng(n)
+    tn, cj = 0.125, 40.0 + rng.uniform(size=batch)
+    idx = np.arange(batch - 1, -1, -1) if batch > 3 else np.arange(batch)   # a permuted list
+    ypred = p["yy0"] + 1e-3 * rng.standard_normal(p["yy0"].shape)
+    ee = 1e-2 * rng.standard_normal(p["yy0"].shape)
+    for reset_ee in (True, False):
+        out = []
+        for fused in (False, True):
+            ctx = problems.make_ctx(p)
+            ctx.upload(idahip.F_YYPREDICT, ypred)
+            ctx.upload(idahip.F_YPPREDICT, p["yp0"])
+            ctx.upload(idahip.F_EE, ee)
+            if fused:
+                rc, info = ctx.nls_sys_setup(tn, cj[idx], reset_ee=reset_ee, idx=idx)
+            else:
+                ctx.nls_sys(tn, cj[idx], reset_ee=reset_ee, idx=idx)
+                rc, info = ctx.nls_lsetup(tn, cj[idx], idx=idx)
+            assert rc == 0 and not info.any()
+            lus = [ctx.download_lu(s) for s in range(batch)]
+            out.append((ctx.download(idahip.F_DELTA), ctx.download(idahip.F_SAVRES), ctx.download(idahip.F_YY),
+                        ctx.download(idahip.F_YP), ctx.download(idahip.F_EE), lus))
+        for a, b in zip(out[0][:5], out[1][:5]):
+            assert np.array_equal(a, b)
+        for (lu_a, piv_a), (lu_b, piv_b) in zip(out[0][5], out[1][5]):
+            assert np.array_equal(lu_a, lu_b) and np.array_equal(piv_a, piv_b)
