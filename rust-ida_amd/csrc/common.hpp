@@ -58,8 +58,7 @@ struct idahip_ctx {
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr;
     double* lu_l11 = nullptr;
-    int lu_variant = 4;  // 4: 64-column super-panels, two rows per lane in the panel kernel, wave-private strips in the
-                         //    trailing kernel (lu_kernels.hpp, default); 3: the same with workgroup-wide 64-row tiles
+    int lu_variant = 3;  // 3: 64-column super-panels, two rows per lane in the panel kernel (lu_kernels.hpp, default)
                          // 2: the same with one row per lane; 0: 32-column panels + rank-32 trailing kernel
                          // 1: row-major work matrix, 16-column sub-panels, rank-64 trailing update (lu_rm.hpp)
 

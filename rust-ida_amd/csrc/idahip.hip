@@ -708,7 +708,7 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 4) return -1;
+    if (!c || variant < 0 || variant > 3) return -1;
     c->lu_variant = variant;
     return 0;
 }

@@ -900,238 +900,19 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     }
 }
 
-// ------------------------------------------------------------------------------------------------ trailing, 64-wide panels
-// Same contract as lu_trail_kernel for panels of 64 columns (n <= 512): half as many sweeps over the trailing matrix,
-// so about half its HBM traffic. One workgroup per (matrix, 64 trailing columns):
+// ------------------------------------------------------------------------------------------------ trailing, 64-wide super-panels
+// Same contract as lu_trail_kernel for super-panels of 64 columns: half as many sweeps over the trailing matrix, so about
+// half its HBM traffic. One workgroup per (matrix, 64 trailing columns):
 //   1. gather the 64 pivot rows of the block into LDS;
 //   2. U12 = L11^-1 A12 in three stages so that only two short chains are serial: wave 0 solves rows 0..31, all four
-//      waves apply those rows to rows 32..63 (8 rows per wave, multipliers through the scalar cache), wave 0 solves
-//      rows 32..63. Every element still receives its updates in ascending pivot order;
-//   3. rank-64 update of each 64-row tile of live rows as two k-chunks of 32 through one LDS multiplier buffer
-//      (49 KB of LDS per workgroup -> three workgroups per CU), 4 x 4 register tile per thread, the next tile's
-//      operands in flight behind the second chunk.
-__global__ __launch_bounds__(256, 3) void lu_trail64_kernel(LuWs w, int k0, int nsys, int ncb) {
-    constexpr int NB = 64, KC = 32, MAXROWS = LU_MAX_N;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
-    if (mi >= nsys) return;
-    const int b = w.idx[mi];
-    if (w.info[b] != 0) return;
-    const int n = w.n;
-    double* __restrict__ A = w.mats + (long)b * w.mstride;
-    const int* __restrict__ live = w.live + (long)b * n;
-    const int* __restrict__ prow = w.prow + (long)b * n + k0;
-    const double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;  // l11ld == 64 here
-
-    const int mrem = n - k0 - NB;  // live rows after this panel (> 0)
-    const int cb0 = k0 + NB + cbi * 64;
-    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-
-    __shared__ __align__(16) double Us[NB][64];
-    __shared__ __align__(16) double Ls[KC][64];
-    __shared__ unsigned short s_live[MAXROWS];
-    __shared__ int s_anyzero;
-
-    for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
-#pragma unroll
-    for (int pass = 0; pass < NB / 4; ++pass) {
-        const int k = pass * 4 + wave;
-        const int pr = ldc(prow + k);
-        Us[k][lane] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
-    }
-    if (t == 0) s_anyzero = 0;
-    // L11 multipliers of pivot rows 0..31 (transposed: [source row kk][target row k]) into the idle tile buffer: a
-    // triangular-solve step then reads them as LDS broadcasts instead of waiting on one scalar load per step
-    auto stage_l11 = [&](const int R0) {
-#pragma unroll
-        for (int i = 0; i < (KC * 64) / 256; ++i) {
-            const int e = i * 256 + t;
-            Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
-        }
-    };
-    stage_l11(0);
-    lds_barrier();
-
-    const int tx = t & 15, ty = t >> 4;
-    const int ntiles = (mrem + 63) >> 6;
-    int col[4];
-    bool cok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cj = ty + 16 * j;
-        cok[j] = cj < ncols;
-        col[j] = cb0 + (cok[j] ? cj : 0);
-    }
-    constexpr int LPT = KC / 4;  // multipliers per thread per k-chunk
-    double lreg[2][LPT], creg[4][4];
-    int crow[4];
-    bool rok[4];
-
-    auto load_tile = [&](int rt) {
-        const int lr = rt * 64 + lane;
-        const int lrow = s_live[lr < mrem ? lr : mrem - 1];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < LPT; ++i) lreg[h][i] = A[(long)(k0 + h * KC + wave * LPT + i) * n + lrow];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ri = rt * 64 + tx + 16 * i;
-            rok[i] = ri < mrem;
-            crow[i] = s_live[rok[i] ? ri : mrem - 1];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) creg[i][j] = A[(long)col[j] * n + crow[i]];
-    };
-
-    // one triangular stage by wave 0: rows [R0, R0+32) of U12 against the diagonal block of L11 they share
-    auto trsm32 = [&](const int R0) {
-        double u[KC];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) u[k] = Us[R0 + k][lane];
-        const bool real = lane < ncols;
-        bool anyz = false;
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            const double ukk = u[kk];
-            const bool z = real && (ukk == 0.0);
-            anyz = anyz || z;
-            if (__ballot(z) == 0ull) {
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k > kk) u[k] -= ukk * Ls[kk][R0 + k];  // a(i,j) -= a_kj * a_ik, ascending kk
-            } else {
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k > kk) {
-                        const double tn = u[k] - ukk * Ls[kk][R0 + k];
-                        u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
-                    }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            Us[R0 + k][lane] = u[k];
-            if (real) A[(long)(cb0 + lane) * n + ldc(prow + R0 + k)] = u[k];
-        }
-        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
-    };
-
-    if (wave == 0) trsm32(0);
-    else load_tile(0);  // waves 1-3: live rows only (untouched by the U12 stores), in flight behind the triangular solves
-    lds_barrier();
-    {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
-        const bool zpath = s_anyzero != 0;
-        double v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = Us[KC + wave * 8 + i][lane];
-        if (!zpath) {
-#pragma unroll
-            for (int kk = 0; kk < KC; ++kk) {
-                const double ut = Us[kk][lane];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] -= ut * Ls[kk][KC + wave * 8 + i];
-            }
-        } else {
-#pragma unroll 4
-            for (int kk = 0; kk < KC; ++kk) {
-                const double ut = Us[kk][lane];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const double tn = v[i] - ut * Ls[kk][KC + wave * 8 + i];
-                    v[i] = (ut != 0.0) ? tn : v[i];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Us[KC + wave * 8 + i][lane] = v[i];
-    }
-    lds_barrier();
-    stage_l11(KC);
-    lds_barrier();
-    if (wave == 0) {
-        trsm32(KC);
-        load_tile(0);
-    }
-    lds_barrier();
-    const bool slow = s_anyzero != 0;
-#ifdef T64_SKIP_TILES
-    if (k0 >= 0) return;
-#endif
-
-    auto chunk = [&](double (&c)[4][4], const int kbase) {
-        if (!slow) {
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                double lv[4], uv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lv[i] = Ls[k][tx + 16 * i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][ty + 16 * j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
-            }
-        } else {
-#pragma unroll 4
-            for (int k = 0; k < KC; ++k) {
-                double lv[4], uv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lv[i] = Ls[k][tx + 16 * i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][ty + 16 * j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double tn = c[i][j] - uv[j] * lv[i];
-                        c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
-                    }
-            }
-        }
-    };
-
-#pragma unroll 1
-    for (int rt = 0; rt < ntiles; ++rt) {
-        lds_barrier();  // the previous tile's second chunk has been read by everyone
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) Ls[wave * LPT + i][lane] = lreg[0][i];
-        lds_barrier();
-        double c[4][4];
-        int srow[4];
-        bool sok[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            srow[i] = crow[i];
-            sok[i] = rok[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
-        }
-        chunk(c, 0);
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) Ls[wave * LPT + i][lane] = lreg[1][i];
-        lds_barrier();
-        if (rt + 1 < ntiles) load_tile(rt + 1);  // in flight behind the second chunk
-        chunk(c, KC);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (cok[j] && sok[i]) A[(long)col[j] * n + srow[i]] = c[i][j];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ trailing, 64-wide panels, wave-private strips
-// lu_trail64_kernel with a different split of the tile work: a wave owns 16-row strips of the block (64 columns wide) and
-// stages the multipliers of ITS rows in its own 4 KB of LDS, so the update loop has no workgroup barrier at all -- waves
-// only meet in the U12 prologue. Per lane a 4 x 4 register tile (rows a + 4i of the strip, columns q + 16j); L and U are
-// stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU ops.
+//      waves apply those rows to rows 32..63 (8 rows per wave), wave 0 solves rows 32..63. Every element still receives
+//      its updates in ascending pivot order; L11 is staged in LDS (one scalar load per solve step was 4x slower);
+//   3. rank-64 update of the live rows in wave-private strips: a wave owns 16-row strips of the block and stages the
+//      multipliers of ITS rows in its own 4 KB of LDS, so the update loop has no workgroup barrier at all -- waves only
+//      meet in the U12 prologue. Per lane a 4 x 4 register tile (rows a + 4i of the strip, columns q + 16j); L and U are
+//      stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU
+//      ops; two k-chunks of 32 through the strip buffer, the next strip's operands in flight behind the second chunk.
+//      49 KB of LDS per workgroup -> three workgroups per CU.
 template <int MAXROWS>
 __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
     constexpr int NB = 64, KC = 32;
@@ -1451,7 +1232,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    const bool two_rows = c->lu_variant >= 3 || n > LU_MAX_N;
+    const bool two_rows = c->lu_variant == 3 || n > LU_MAX_N;
     if (c->lu_variant >= 2 || n > LU_MAX_N) {
         // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
         // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
@@ -1483,10 +1264,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 const int ncb = (ntrail + 63) / 64;
                 if (n > LU_MAX_N)
                     hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-                else if (c->lu_variant == 4)
-                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 else
-                    hipLaunchKernelGGL(lu_trail64_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             }
         }
         hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32);
