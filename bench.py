@@ -71,6 +71,31 @@ def profiled_traffic(cls):
     return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
 
 
+def roofline(dom, d, alg_bytes, achieved, n):
+    """The `roofline` object of the JSON line for the kernel class with the most device time. achieved = algorithmic bytes
+    per launch / average launch duration (HIP events on the ctx stream, timed region); traffic = measured HBM bytes per
+    launch, i.e. the committed PMC figure per system x the systems one launch of this run processed."""
+    spl = d["systems"] / max(1, d["launches"])
+    tr = profiled_traffic(dom)
+    extra = {}
+    if dom == "lu" and d["ms"] > 0:
+        # the reference-exact elimination is an unfused mul + sub per update: 2 fp64 VALU ops, ~n^3/3 updates per matrix;
+        # ceiling = 256 CUs x 64 lanes x 2.4 GHz / 2 ops
+        upd = (n ** 3 / 3.0) * d["systems"] / (d["ms"] * 1e-3)
+        peak = 256 * 64 * 2.4e9 / 2.0
+        extra = {"valu": {"achieved": round(upd / 1e12, 3), "peak": round(peak / 1e12, 2), "unit": "T updates/s (mul + sub, fp64)",
+                          "frac": round(upd / peak, 4)}}
+    return {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], **extra, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None if tr is None else int(tr["hbm_bytes_per_system"] * spl),
+            "traffic_bytes_per_system": None if tr is None else tr["hbm_bytes_per_system"],
+            "traffic_source": None if tr is None else tr["source"],
+            "algorithmic_bytes_per_launch": int(alg_bytes * spl), "algorithmic_bytes_per_system": alg_bytes,
+            "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "systems_per_launch": round(spl, 1),
+            "note": "a launch of the lu class is one batched getrf (all its kernel launches); for the LU the fp64 VALU ceiling "
+                    "binds before HBM (DESIGN.md section 4)"}
+
+
 class Lane:
     """Continuous lock-step integration of one contiguous slice of the rank's systems, with restart at t = 1."""
 
@@ -290,13 +315,7 @@ def main():
                        "sharding": "independent systems, contiguous block per rank, no collective",
                        "lanes_per_gpu": args.lanes},
             "newton_iters_timed": iters_all,
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": profiled_traffic(dom),
-                         "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4),
-                         "algorithmic_bytes_per_system": ab[dom],
-                         "systems_per_launch": round(d["systems"] / max(1, d["launches"]), 1),
-                         "note": "achieved = algorithmic bytes of the systems processed / device time of the class (HIP events "
-                                 "on the ctx stream, timed region); for the LU the fp64 VALU ceiling binds before HBM (DESIGN.md section 4)"},
+            "roofline": roofline(dom, d, ab[dom], achieved, args.n),
             "kernel_classes_rank0": classes,
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
