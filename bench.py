@@ -240,7 +240,7 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         ncpu = max(1, min(cores, 64))
-        nsmall = min(args.batch, 4 * ncpu)
+        nsmall = min(args.batch, 16 * ncpu)  # ~10 s of wall time on 64 threads
         small = {k: (v[:nsmall] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == args.batch else v) for k, v in prob.items()}
         cpu = cpu_baseline(small, ncpu)
 
