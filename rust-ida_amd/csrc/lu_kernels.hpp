@@ -730,7 +730,7 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
 //   and 4 U entries from LDS (conflict-free b64 reads) for 16 updates -> VALU-bound, ~100 VGPRs, 3 workgroups per CU.
 // No Ubuf round trip, no per-lane operand broadcast; the matrix is touched in coalesced column segments only
 // (the pivot-row gather/scatter is the one strided access: NB x 64 elements per workgroup).
-template <int NB, int MAXROWS>
+template <int NB, int MAXROWS, int CJ>
 __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit, int l11off) {
     // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so the column blocks of one matrix are
     // given ids with equal (id & 7) and adjacent (id >> 3): they run on one XCD at about the same time and share the
@@ -777,20 +777,20 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     //    a __syncthreads() would also drain the tile stores, which nobody in this launch reads).
     const int tx = t & 15, ty = t >> 4;
     const int ntiles = (mrem + 63) >> 6;
-    int col[4];
-    bool cok[4];
+    int col[CJ];  // CJ = 4: a full block of 64 columns; CJ = 2: at most 32 (the narrow update inside a super-panel)
+    bool cok[CJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CJ; ++j) {
         const int cj = ty + 16 * j;
         cok[j] = cj < ncols;
         col[j] = cb0 + (cok[j] ? cj : 0);
     }
     constexpr int LPT = NB / 4;  // multipliers per thread per tile
-    double lreg[LPT], creg[4][4];
+    double lreg[LPT], creg[4][CJ];
     int crow[4];
     bool rok[4];
 
-    auto load_tile = [&](int rt, double (&lr_)[LPT], double (&cr_)[4][4], int (&crow_)[4], bool (&rok_)[4]) {
+    auto load_tile = [&](int rt, double (&lr_)[LPT], double (&cr_)[4][CJ], int (&crow_)[4], bool (&rok_)[4]) {
         const int lr = rt * 64 + lane;
         const int lrow = s_live[lr < mrem ? lr : mrem - 1];
 #pragma unroll
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
             crow_[i] = s_live[rok_[i] ? ri : mrem - 1];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < CJ; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) cr_[i][j] = A[(long)col[j] * n + crow_[i]];
     };
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Ls[buf][wave * LPT + i][lane] = lreg[i];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        double c[4][4];
+        double c[4][CJ];
         int srow[4];
         bool sok[4];
 #pragma unroll
@@ -859,32 +859,32 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
             srow[i] = crow[i];
             sok[i] = rok[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
+            for (int j = 0; j < CJ; ++j) c[i][j] = creg[i][j];
         }
         if (rt + 1 < ntiles) load_tile(rt + 1, lreg, creg, crow, rok);  // in flight behind the arithmetic below
         if (!slow) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                double lv[4], uv[4];
+                double lv[4], uv[CJ];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lv[i] = Ls[buf][k][tx + 16 * i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) uv[j] = Us[k][ty + 16 * j];
+                for (int j = 0; j < CJ; ++j) uv[j] = Us[k][ty + 16 * j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < CJ; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
             }
         } else {
 #pragma unroll 4
             for (int k = 0; k < NB; ++k) {
-                double lv[4], uv[4];
+                double lv[4], uv[CJ];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lv[i] = Ls[buf][k][tx + 16 * i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) uv[j] = Us[k][ty + 16 * j];
+                for (int j = 0; j < CJ; ++j) uv[j] = Us[k][ty + 16 * j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < CJ; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const double tn = c[i][j] - uv[j] * lv[i];
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < CJ; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (cok[j] && sok[i]) A[(long)col[j] * n + srow[i]] = c[i][j];
@@ -1248,14 +1248,14 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
                     hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
                     if (k0 + lb + NBS < cend)
-                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
                                            cend, lb * 65);
                 }
             } else {
             if (two_rows) panel2(k0, 0); else panel(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
-                hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0);
+                hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 2>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0);
                 if (two_rows) panel2(k0 + NB, NB); else panel(k0 + NB, NB);
             }
             }
@@ -1277,7 +1277,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int ntrail = n - k0 - NB;
         if (ntrail > 0) {
             const int ncb = (ntrail + 63) / 64;
-            hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n, 0);
+            hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 4>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n, 0);
         }
     }
     const int cpb = 32;
