@@ -42,6 +42,8 @@ struct LuWs {
     int* info;         // [batch]   0 | 1-based zero-pivot column
     double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
     int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
+    double* out;       // factors in the reference layout (rows at their pivoted positions), column-major n x n
+    long ostride;      // elements between consecutive systems in out
 };
 constexpr int L11_STRIDE = 64 * 64;  // elements per system in LuWs::l11
 
@@ -833,10 +835,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
             }
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            Us[k][lane] = u[k];
-            if (real) A[(long)(cb0 + lane) * n + ldc(prow + k)] = u[k];
-        }
+        for (int k = 0; k < NB; ++k) Us[k][lane] = u[k];
         if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
         load_tile(0, lreg, creg, crow, rok);
     } else {
@@ -844,6 +843,18 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     }
     __syncthreads();
     const bool slow = s_anyzero != 0;
+    // The solved pivot rows are final and nothing reads them in the work matrix again: they go straight to their place in
+    // the factors -- pivot k of this panel is row k0 + k of the reference layout, so a column's NB entries are one
+    // contiguous store (one row per lane) instead of NB eight-byte stores into NB different sectors of the work matrix;
+    // lu_finalize_kernel skips this region.
+    {
+        double* __restrict__ O = w.out + (long)b * w.ostride;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            if (cc < ncols && lane < NB) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][cc];
+        }
+    }
 
 #pragma unroll 1
     for (int rt = 0; rt < ntiles; ++rt) {
@@ -1020,10 +1031,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             }
         }
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            Us[R0 + k][pl] = u[k];
-            if (real) A[(long)(cb0 + lane) * n + ldc(prow + R0 + k)] = u[k];
-        }
+        for (int k = 0; k < KC; ++k) Us[R0 + k][pl] = u[k];
         if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
     };
 
@@ -1071,6 +1079,18 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     }
     lds_barrier();  // last workgroup barrier: from here on a wave touches only Us (read-only) and its own strip of Ls
     const bool slow = s_anyzero != 0;
+    // The solved pivot rows are final and nothing reads them in the work matrix again: they go straight to their place in
+    // the factors -- pivot k of this super-panel is row k0 + k of the reference layout, so a column's 64 entries are one
+    // contiguous 512-byte store (one row per lane) instead of 64 eight-byte stores into 64 different sectors of the work
+    // matrix; lu_finalize_kernel skips this region.
+    {
+        double* __restrict__ O = w.out + (long)b * w.ostride;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;  // column of the block; its LDS slot is 4 * (cc & 15) + (cc >> 4)
+            if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
+        }
+    }
     double (*__restrict__ Lw)[16] = reinterpret_cast<double (*)[16]>(&Ls[0][0] + wave * (KC * 16));
 
     auto chunk = [&](double (&c)[4][4], const int kbase) {
@@ -1139,8 +1159,10 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 
 // ------------------------------------------------------------------------------------------------ finalize
 // out(pos[r], j) = work(r, j); perm[pos[r]] = r. One workgroup per (matrix, column group).
+// sp = panel width of the pipeline: its trailing kernels already wrote the U rows right of their panel into `out`; those
+// entries are skipped here -- the work matrix no longer holds them (sp_lead: see below).
 __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __restrict__ out, long ostride, int* __restrict__ perm,
-                                                          int cols_per_block) {
+                                                          int cols_per_block, int sp, int sp_lead) {
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -1152,7 +1174,14 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         const int p = pos[r];
         if (blockIdx.y == 0 && perm) perm[(long)b * n + p] = r;
-        for (int j = jbeg; j < jend; ++j) O[(long)j * n + p] = A[(long)j * n + r];
+        int je = jend;
+        if (sp > 0) {
+            // large n: the leading 64-column super-panels (more than LU_MAX_N live rows) are built from sp_lead-column panels
+            const int w_ = (sp_lead > 0 && n - (p & ~63) > LU_MAX_N) ? sp_lead : sp;
+            const int spend = (p / w_ + 1) * w_;  // first column right of the panel that made row p a pivot row
+            je = je < spend ? je : spend;
+        }
+        for (int j = jbeg; j < je; ++j) O[(long)j * n + p] = A[(long)j * n + r];
     }
 }
 
@@ -1217,7 +1246,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info;
-    w.l11 = c->lu_l11;
+    w.l11 = c->lu_l11; w.out = out; w.ostride = ostride;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;
     constexpr int NB = LU_NB;
@@ -1268,7 +1297,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                     hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             }
         }
-        hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32);
+        hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB, n > LU_MAX_N ? 8 : 0);
         return 0;
     }
     w.l11ld = NB;
@@ -1281,7 +1310,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         }
     }
     const int cpb = 32;
-    hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + cpb - 1) / cpb), dim3(256), 0, c->stream, w, out, ostride, perm, cpb);
+    hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + cpb - 1) / cpb), dim3(256), 0, c->stream, w, out, ostride, perm, cpb, NB, 0);
     return 0;
 }
 
