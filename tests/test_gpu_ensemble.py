@@ -199,3 +199,31 @@ def test_sys_setup_in_one_call_equals_sys_then_lsetup(kind, n, batch):
             assert np.array_equal(a, b)
         for (lu_a, piv_a), (lu_b, piv_b) in zip(out[0][5], out[1][5]):
             assert np.array_equal(lu_a, lu_b) and np.array_equal(piv_a, piv_b)
+
+
+def test_singular_jacobian_fails_like_the_oracle_and_spares_the_batch():
+    """One system whose Newton matrix B + cj A has an exactly zero column for every cj: its linear setup fails at every
+    attempt (recoverable, the step size is cut, then the step fails for good); the oracle walks the same path, and the
+    other systems of the batch are untouched by it."""
+    import idahip
+    from idahip import problems
+    n, batch, bad = 12, 4, 2
+    p = problems.linear_dense(n=n, batch=batch)
+    p["A"][bad, 5, :] = 0.0   # storage is [col][row]: column 5 of A and of B
+    p["B"][bad, 5, :] = 0.0
+    ctx = problems.make_ctx(p)
+    ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+    status, tret = ens.solve(0.1)
+    ref = run_oracle(p, touts=[0.1])
+    assert np.array_equal(status, ref["status"])
+    assert status[bad] < 0 and (np.delete(status, bad) == 0).all()
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    good = np.arange(batch) != bad
+    assert np.array_equal(ens.yy()[good], ref["yy"][0][good])
+    # the healthy systems equal a run without the bad one
+    q = {k: (v[good] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == batch else v) for k, v in p.items()}
+    ens2 = idahip.Ensemble(problems.make_ctx(q), q["yy0"], q["yp0"])
+    ens2.solve(0.1)
+    assert np.array_equal(ens2.yy(), ens.yy()[good])
