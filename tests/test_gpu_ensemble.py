@@ -227,3 +227,18 @@ def test_singular_jacobian_fails_like_the_oracle_and_spares_the_batch():
     ens2 = idahip.Ensemble(problems.make_ctx(q), q["yy0"], q["yp0"])
     ens2.solve(0.1)
     assert np.array_equal(ens2.yy(), ens.yy()[good])
+
+
+def test_newton_convergence_failures_follow_the_reference_path():
+    """Lorenz at r = 400 with very loose tolerances: some steps are so long that Newton does not converge in four
+    iterations even with a fresh Jacobian (ncfn > 0: the step is repeated with h/4, src/lib.rs handle_n_flag). State and
+    every counter stay bit-identical to the oracle."""
+    from idahip import problems
+    p = problems.lorenz63(batch=512)
+    pr, rr, bb = 10.0, 400.0, 8.0 / 3.0
+    p["params"][:, 1] = rr
+    y0 = p["yy0"]
+    p["yp0"] = np.stack([pr * (y0[:, 1] - y0[:, 0]), y0[:, 0] * (rr - y0[:, 2]) - y0[:, 1], y0[:, 0] * y0[:, 1] - bb * y0[:, 2]], axis=1)
+    p["rtol"], p["atol"] = 0.3, np.array([0.1])
+    ens, ref = check(p, touts=p["touts"][:20])
+    assert ref["counters"]["ncfn"].sum() > 0 and ref["counters"]["netf"].sum() > 0
