@@ -362,6 +362,10 @@ class Ensemble:
     def set_max_num_steps(self, mxstep):
         self.E.idaens_set_max_num_steps(self.h, int(mxstep))
 
+    def set_max_ord(self, maxord):
+        if self.E.idaens_set_max_ord(self.h, int(maxord)) != 0:
+            raise IdaHipError("set_max_ord(%d) rejected" % maxord)
+
     def solve(self, tout, itask=0, max_rounds=0):
         tret = np.zeros(self.ctx.batch)
         status = np.zeros(self.ctx.batch, dtype=np.int32)

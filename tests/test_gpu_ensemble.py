@@ -242,3 +242,29 @@ def test_newton_convergence_failures_follow_the_reference_path():
     p["rtol"], p["atol"] = 0.3, np.array([0.1])
     ens, ref = check(p, touts=p["touts"][:20])
     assert ref["counters"]["ncfn"].sum() > 0 and ref["counters"]["netf"].sum() > 0
+
+
+@pytest.mark.parametrize("maxord", [1, 2, 3])
+def test_max_order_limit(maxord):
+    """Ida::set_max_ord: the order selection is capped (complete_step / test_error branches on kk == maxord), steps and
+    state still bit-identical to the oracle with the same cap (a low cap needs many more steps: mxstep is raised on both
+    sides)."""
+    import idahip
+    from idahip import problems
+    p = problems.linear_dense(n=20, batch=3)
+    touts = p["touts"][:2]
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    ens.set_max_ord(maxord)
+    ens.set_max_num_steps(200000)
+    for t in touts:
+        st, _ = ens.solve(float(t))
+        assert (st == 0).all()
+    assert (ens.counter("kused") <= maxord).all()
+    for s in range(3):
+        o = O.OracleIda("linear_dense", 20, p["yy0"][s], p["yp0"][s], p["rtol"], p["atol"], A=p["A"][s], B=p["B"][s], c=p["c"][s])
+        o.set("maxord", maxord)
+        o.set("mxstep", 200000)
+        for t in touts:
+            assert o.solve(float(t))[0] == 0
+        assert np.array_equal(o.getv("yy"), ens.yy()[s]) and np.array_equal(o.getv("yp"), ens.yp()[s])
+        assert o.get("nst") == ens.counter("nst")[s] and o.get("nni") == ens.counter("nni")[s]
