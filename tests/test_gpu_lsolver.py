@@ -193,3 +193,35 @@ def test_wrms_reference_golden():
     ctx = idahip.Ctx("linear_dense", n, 1)
     got = ctx.wrms(ctx.dev_array(np.full((1, n), g["x"])), ctx.dev_array(np.full((1, n), g["w"])))
     assert got[0] == g["expect"] == 0.25
+
+
+def test_empty_and_invalid_system_lists():
+    """nsys = 0 is a no-op for every entry point that takes a list; ids outside the batch or an unsupported size are
+    refused with an error message before anything is launched (shapes are checked on the host: a bad index would be an
+    out-of-bounds access on the device)."""
+    import ctypes as C
+    import idahip
+    n, B = 24, 3
+    rng = np.random.default_rng(0)
+    mats = rng.standard_normal((B, n, n))
+    ctx = idahip.Ctx("linear_dense", n, B)
+    ctx.set_lu_variant(LU_VARIANT)
+    dA = ctx.dev_array(colmajor(mats))
+    dP = ctx.dev_empty(8 * B * n)
+    before = ctx.to_host(dA, (B, n, n)).copy()
+    empty = np.zeros(0, dtype=np.int32)
+    rc, info = ctx.ls_setup(dA, dP, empty)
+    assert rc == 0 and info.size == 0
+    assert np.array_equal(ctx.to_host(dA, (B, n, n)), before)
+    assert ctx.wrms(dA, dA, idx=empty).size == 0
+    ctx.nls_sys(0.0, 1.0, True, idx=empty)
+    rc, info = ctx.nls_lsetup(0.0, 1.0, idx=empty)
+    assert rc == 0
+    for bad in ([B], [-1], [0, 1, 7]):
+        with pytest.raises(idahip.IdaHipError, match="out of range"):
+            ctx.ls_setup(dA, dP, bad)
+        with pytest.raises(idahip.IdaHipError, match="out of range"):
+            ctx.nls_sys(0.0, 1.0, True, idx=bad)
+    assert np.array_equal(ctx.to_host(dA, (B, n, n)), before)
+    with pytest.raises(idahip.IdaHipError):
+        idahip.Ctx("linear_dense", 5000, 1).ls_setup(ctx.dev_empty(8), ctx.dev_empty(8), [0])  # n > 4096: refused
