@@ -35,6 +35,7 @@ enum {
     IDAENS_ERR_FAIL = -3,
     IDAENS_CONV_FAIL = -4,
     IDAENS_LSETUP_FAIL = -6,
+    IDAENS_CLOSE_ROOTS = -10, /* IdaError::CloseRoots (impl_r_check.rs:199) */
     IDAENS_ILL_INPUT = -22,
     IDAENS_BAD_T = -26
 };
@@ -48,6 +49,13 @@ const char* idaens_last_error(const idaens* e);
 /* optional inputs (the reference has defaults only, src/lib.rs:309-321; setters follow C IDA's names) */
 int idaens_set_max_num_steps(idaens* e, long mxstep); /* 0 = unlimited; default 500 (MXSTEP_DEFAULT) */
 int idaens_set_max_ord(idaens* e, int maxord);        /* 1..5, default 5 */
+/* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
+ * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call
+ * before the first solve; idaens_solve then reports IDAENS_ROOT_RETURN with tret = the root, yy/yp = the solution there,
+ * and idaens_get_roots gives rootsfound (ida_iroots: -1/0/+1 per function). Root closures cannot cross the C ABI, so the
+ * functions are this parametrised family. */
+int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds);
+int idaens_get_roots(const idaens* e, int32_t* out /* [batch][nroots] */);
 
 /* Ida::solve(tout, &mut tret, itask) for every system (src/impl_solve.rs:69-376). hTret/hStatus: [batch].
  * max_rounds > 0 bounds the number of lock-step attempt rounds (systems still stepping report IDAENS_UNFINISHED and
@@ -57,7 +65,8 @@ int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hSta
 /* getters (src/ida_io.rs:11-117), arrays of length batch */
 enum {
     IDAENS_C_NST = 0, IDAENS_C_NRE = 1, IDAENS_C_NJE = 2, IDAENS_C_NSETUPS = 3, IDAENS_C_NNI = 4, IDAENS_C_NETF = 5,
-    IDAENS_C_NCFN = 6, IDAENS_C_NATTEMPTS = 7, IDAENS_C_NLS_NCONVFAILS = 8, IDAENS_C_KUSED = 9, IDAENS_C_KK = 10
+    IDAENS_C_NCFN = 6, IDAENS_C_NATTEMPTS = 7, IDAENS_C_NLS_NCONVFAILS = 8, IDAENS_C_KUSED = 9, IDAENS_C_KK = 10,
+    IDAENS_C_NGE = 11 /* root-function evaluations (ida_nge) */
 };
 int idaens_get_counter(const idaens* e, int which, int64_t* out);
 enum { IDAENS_R_TN = 0, IDAENS_R_HUSED = 1, IDAENS_R_HH = 2, IDAENS_R_H0U = 3, IDAENS_R_TOLSF = 4 };

@@ -77,6 +77,13 @@ struct Sys {
     int status = 0;
     double tret = 0.0;
     bool dead = false;  // a fatal IdaError was returned: later solve calls report it again
+    // --- root finding (src/lib.rs:225-244, src/impl_r_check.rs); the vectors have nrtfn entries when roots are enabled
+    std::vector<double> glo, ghi, grout, iroots;
+    std::vector<uint8_t> gactive;
+    bool irfnd = false;
+    double tlo = 0.0, thi = 0.0, trout = 0.0, ttol = 0.0, toutc = 0.0;
+    int taskc = 0;
+    long nge = 0;
 };
 
 }  // namespace
@@ -93,6 +100,12 @@ struct idaens {
     int64_t total_rounds = 0;
     int trace_sys = -1;
     std::vector<double> trace;
+    // root functions g_i(t, y, y') = y[rt_comp[i]] - rt_thr[i] (the form of the reference's Roberts example,
+    // src/sample_problems/roberts.rs: g0 = y0 - 1e-4, g1 = y2 - 0.01); nrtfn == 0: no root finding
+    int nrtfn = 0;
+    std::vector<int32_t> rt_comp;
+    std::vector<double> rt_thr;
+    std::vector<double> hy, hyp;  // host copies of one system's y, y' for the root functions
     // scratch for list calls
     std::vector<int32_t> idx, ia, ib;
     std::vector<double> da, db, dc, dd;
@@ -387,6 +400,227 @@ int flush_solutions(idaens* e, SolList& sl) {
     return 0;
 }
 
+// ---------------------------------------------------------------- root finding (src/impl_r_check.rs:32-576)
+// Roots are rare events of single systems: the bracketing runs system by system on the host, with the device
+// interpolating y(t), y'(t) (idahip_get_solution) and the two vectors coming back for the root functions.
+void root_fn(const idaens* e, const double* y, double* g) {
+    for (int i = 0; i < e->nrtfn; ++i) g[i] = y[e->rt_comp[i]] - e->rt_thr[i];
+}
+
+// get_solution(t) of system b on the device (yy, yp of that system become y(t), y'(t), lib.rs:1274), copy to e->hy, e->hyp
+int interp_now(idaens* e, int b, double t) {
+    Sys& s = e->sys[b];
+    int kord = 1;
+    const int rc = get_solution_coeffs(s, t, &kord);
+    if (rc) return rc;
+    const int32_t ib = b, ko = kord;
+    ENS_CALL(e, idahip_get_solution(e->ctx, &ko, s.cvals, s.dvals, &ib, 1));
+    ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YY, b, 1, e->hy.data()));
+    ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YP, b, 1, e->hyp.data()));
+    return 0;
+}
+
+// impl_r_check.rs:32-115 -- at the first call, before phi[1] is scaled by hh
+int r_check1(idaens* e, int b) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    Sys& s = e->sys[b];
+    const int n = e->n, nr = e->nrtfn;
+    std::fill(s.iroots.begin(), s.iroots.end(), 0.0);
+    s.tlo = s.tn;
+    s.ttol = (std::fabs(s.tn) + std::fabs(s.hh)) * eps * 100.0;
+    ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_PHI0, b, 1, e->hy.data()));
+    ENS_CALL(e, idahip_download(e->ctx, (idahip_field)(IDAHIP_F_PHI0 + 1), b, 1, e->hyp.data()));
+    root_fn(e, e->hy.data(), s.glo.data());
+    s.nge = 1;
+    bool zroot = false;
+    for (int i = 0; i < nr; ++i)
+        if (std::fabs(s.glo[i]) == 0.0) {
+            s.gactive[i] = 0;
+            zroot = true;
+        }
+    if (zroot) {
+        const double hratio = std::fmax(s.ttol / std::fabs(s.hh), 0.1);
+        const double smallh = hratio * s.hh;
+        for (int i = 0; i < n; ++i) e->hy[i] = e->hy[i] + smallh * e->hyp[i];  // yy = phi[0] + smallh * phi[1]
+        ENS_CALL(e, idahip_upload(e->ctx, IDAHIP_F_YY, b, 1, e->hy.data()));
+        root_fn(e, e->hy.data(), s.ghi.data());
+        s.nge += 1;
+        for (int i = 0; i < nr; ++i)
+            if (!s.gactive[i] && std::fabs(s.ghi[i]) != 0.0) {
+                s.gactive[i] = 1;
+                s.glo[i] = s.ghi[i];
+            }
+    }
+    return 0;
+}
+
+// impl_r_check.rs:117-219 -- on re-entry after a root return. Returns IDAENS_UNFINISHED (continue), ROOT_RETURN or < 0.
+int r_check2(idaens* e, int b) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    Sys& s = e->sys[b];
+    const int n = e->n, nr = e->nrtfn;
+    if (!s.irfnd) return IDAENS_UNFINISHED;
+    int rc = interp_now(e, b, s.tlo);
+    if (rc) return rc;
+    root_fn(e, e->hy.data(), s.glo.data());
+    s.nge += 1;
+    std::fill(s.iroots.begin(), s.iroots.end(), 0.0);
+    bool zroot = false;
+    for (int i = 0; i < nr; ++i)
+        if (s.gactive[i] && std::fabs(s.glo[i]) == 0.0) {
+            zroot = true;
+            s.iroots[i] = 1.0;
+        }
+    if (zroot) {
+        s.ttol = (std::fabs(s.tn) + std::fabs(s.hh)) * eps * 100.0;
+        const double smallh = s.ttol * signum(s.hh);
+        const double tplus = s.tlo + smallh;
+        if ((tplus - s.tn) * s.hh >= 0.0) {
+            const double hratio = smallh / s.hh;
+            std::vector<double> p1(n);
+            ENS_CALL(e, idahip_download(e->ctx, (idahip_field)(IDAHIP_F_PHI0 + 1), b, 1, p1.data()));
+            for (int i = 0; i < n; ++i) e->hy[i] = e->hy[i] + hratio * p1[i];  // yy += hratio * phi[1]
+            ENS_CALL(e, idahip_upload(e->ctx, IDAHIP_F_YY, b, 1, e->hy.data()));
+        } else {
+            rc = interp_now(e, b, tplus);
+            if (rc) return rc;
+        }
+        root_fn(e, e->hy.data(), s.ghi.data());
+        s.nge += 1;
+        bool zroot2 = false;
+        for (int i = 0; i < nr; ++i) {
+            if (!s.gactive[i]) continue;
+            if (std::fabs(s.ghi[i]) == 0.0) {
+                if (s.iroots[i] > 0.0) return IDAENS_CLOSE_ROOTS;
+                zroot2 = true;
+                s.iroots[i] = 1.0;
+            } else if (s.iroots[i] > 0.0) {
+                s.glo[i] = s.ghi[i];
+            }
+        }
+        if (zroot2) return IDAENS_ROOT_RETURN;
+    }
+    return IDAENS_UNFINISHED;
+}
+
+void scan_roots(const idaens* e, const Sys& s, const std::vector<double>& gval, bool first, bool* zroot, bool* sgnchg, int* imax) {
+    double maxfrac = 0.0;
+    *zroot = false;
+    *sgnchg = false;
+    for (int i = 0; i < e->nrtfn; ++i) {
+        if (!s.gactive[i]) continue;
+        const bool rootdir_glo_neg = 0.0 * s.glo[i] <= 0.0;  // rootdir is 0 (no setter in the reference, lib.rs:372)
+        if (first) {  // impl_r_check.rs:361-383
+            if (std::fabs(gval[i]) == 0.0) {
+                if (rootdir_glo_neg) *zroot = true;
+                continue;
+            }
+        } else if (std::fabs(gval[i]) == 0.0 && rootdir_glo_neg) {  // impl_r_check.rs:486-504
+            *zroot = true;
+            continue;
+        }
+        if (s.glo[i] * gval[i] < 0.0 && rootdir_glo_neg) {
+            const double gfrac = std::fabs(gval[i] / (gval[i] - s.glo[i]));
+            if (gfrac > maxfrac) {
+                *sgnchg = true;
+                maxfrac = gfrac;
+                *imax = i;
+            }
+        }
+    }
+}
+
+// impl_r_check.rs:343-576 (modified secant / Illinois). Returns IDAENS_UNFINISHED (no root), ROOT_RETURN or < 0.
+int root_find(idaens* e, int b) {
+    Sys& s = e->sys[b];
+    const int nr = e->nrtfn;
+    int imax = 0;
+    bool zroot, sgnchg;
+    scan_roots(e, s, s.ghi, true, &zroot, &sgnchg, &imax);
+    if (!sgnchg) {
+        s.trout = s.thi;
+        s.grout = s.ghi;
+        if (!zroot) return IDAENS_UNFINISHED;
+        for (int i = 0; i < nr; ++i) {
+            s.iroots[i] = 0.0;
+            if (s.gactive[i] && std::fabs(s.ghi[i]) == 0.0 && 0.0 * s.glo[i] <= 0.0) s.iroots[i] = signum(s.glo[i]);
+        }
+        return IDAENS_ROOT_RETURN;
+    }
+    double alph = 1.0;
+    int side = 0, sideprev = -1;
+    for (;;) {
+        if (std::fabs(s.thi - s.tlo) <= s.ttol) break;
+        if (sideprev == side) alph = (side == 2) ? alph * 2.0 : alph * 0.5;
+        else alph = 1.0;
+        double tmid = s.thi - (s.thi - s.tlo) * s.ghi[imax] / (s.ghi[imax] - alph * s.glo[imax]);
+        if (std::fabs(tmid - s.tlo) < 0.5 * s.ttol) {
+            const double fracint = std::fabs(s.thi - s.tlo) / s.ttol;
+            const double fracsub = (fracint > 5.0) ? 0.1 : 0.5 / fracint;
+            tmid = s.tlo + fracsub * (s.thi - s.tlo);
+        }
+        if (std::fabs(s.thi - tmid) < 0.5 * s.ttol) {
+            const double fracint = std::fabs(s.thi - s.tlo) / s.ttol;
+            const double fracsub = (fracint > 5.0) ? 0.1 : 0.5 / fracint;
+            tmid = s.thi - fracsub * (s.thi - s.tlo);
+        }
+        const int rc = interp_now(e, b, tmid);
+        if (rc) return rc;
+        root_fn(e, e->hy.data(), s.grout.data());
+        s.nge += 1;
+        sideprev = side;
+        scan_roots(e, s, s.grout, false, &zroot, &sgnchg, &imax);
+        if (sgnchg) {
+            s.thi = tmid;
+            s.ghi = s.grout;
+            side = 1;
+            if (std::fabs(s.thi - s.tlo) <= s.ttol) break;
+            continue;
+        }
+        if (zroot) {
+            s.thi = tmid;
+            s.ghi = s.grout;
+            break;
+        }
+        s.tlo = tmid;
+        s.glo = s.grout;
+        side = 2;
+        if (std::fabs(s.thi - s.tlo) <= s.ttol) break;
+    }
+    s.trout = s.thi;
+    s.grout = s.ghi;
+    for (int i = 0; i < nr; ++i) {
+        s.iroots[i] = 0.0;
+        if (s.gactive[i] && 0.0 * s.glo[i] <= 0.0 && (std::fabs(s.ghi[i]) == 0.0 || s.glo[i] * s.ghi[i] < 0.0))
+            s.iroots[i] = signum(s.glo[i]);
+    }
+    return IDAENS_ROOT_RETURN;
+}
+
+// impl_r_check.rs:221-280 -- after a successful step. Returns IDAENS_UNFINISHED (no root), ROOT_RETURN or < 0.
+int r_check3(idaens* e, int b) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    Sys& s = e->sys[b];
+    if (s.taskc == IDAENS_ONE_STEP) s.thi = s.tn;
+    else s.thi = ((s.toutc - s.tn) * s.hh >= 0.0) ? s.tn : s.toutc;
+    int rc = interp_now(e, b, s.thi);
+    if (rc) return rc;
+    root_fn(e, e->hy.data(), s.ghi.data());
+    s.nge += 1;
+    s.ttol = (std::fabs(s.tn) + std::fabs(s.hh)) * eps * 100.0;
+    const int ier = root_find(e, b);
+    if (ier < 0) return ier;
+    for (int i = 0; i < e->nrtfn; ++i)
+        if (!s.gactive[i] && s.grout[i] != 0.0) s.gactive[i] = 1;
+    s.tlo = s.trout;
+    s.glo = s.grout;
+    if (ier == IDAENS_ROOT_RETURN) {
+        rc = interp_now(e, b, s.trout);
+        if (rc) return rc;
+    }
+    return ier;
+}
+
 // ---------------------------------------------------------------- the batched Newton solve (newton.rs:51-167)
 // `act`: systems taking a step attempt this round, with s.call_lsetup decided. Sets s.nls_ret.
 int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
@@ -628,6 +862,23 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, double tout, int itask, 
             s.ewt_bad = bad[q] != 0;
             s.nstloc += 1;
             s.ph = PH_LOOP_TOP;
+            if (e->nrtfn > 0) {  // impl_solve.rs:343-356
+                const int ier = r_check3(e, b);
+                if (ier < 0) {
+                    s.status = ier;
+                    s.dead = true;
+                    s.ph = PH_IDLE;
+                    continue;
+                }
+                if (ier == IDAENS_ROOT_RETURN) {
+                    s.irfnd = true;
+                    s.tretlast = s.tlo;
+                    s.tret = s.tlo;
+                    s.status = IDAENS_ROOT_RETURN;
+                    s.ph = PH_IDLE;
+                    continue;
+                }
+            }
             const int istate = stop_test2(s, b, tout, itask, sl);
             if (istate != IDAENS_UNFINISHED) {
                 s.status = istate;
@@ -729,6 +980,11 @@ int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hSta
                 ok.push_back(fresh[q]);
                 fac.push_back(s.hh);
             }
+            if (e->nrtfn > 0)
+                for (int b : ok) {  // impl_solve.rs:157-159
+                    const int rc1 = r_check1(e, b);
+                    if (rc1) return rc1;
+                }
             if (!ok.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, fac.data(), ok.data(), (int)ok.size()));  // phi[1] = hh*y'
         }
     }
@@ -742,6 +998,49 @@ int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hSta
         }
         if (s.dead || !s.setup_done) continue;  // earlier fatal error / ILL_INPUT at the first call: status is sticky
         s.nstloc = 0;
+        if (itask == IDAENS_NORMAL) s.toutc = tout;
+        s.taskc = itask;
+        if (s.nst > 0 && e->nrtfn > 0) {
+            const double eps_ = std::numeric_limits<double>::epsilon();
+            const bool irfndp = s.irfnd;
+            int ier = r_check2(e, b);
+            if (ier < 0) {
+                s.status = ier;
+                s.dead = true;
+                continue;
+            }
+            if (ier == IDAENS_ROOT_RETURN) {
+                s.tretlast = s.tlo;
+                s.tret = s.tlo;
+                s.status = IDAENS_ROOT_RETURN;
+                continue;
+            }
+            const double troundoff = (std::fabs(s.tn) + std::fabs(s.hh)) * eps_ * 100.0;
+            if (std::fabs(s.tn - s.tretlast) > troundoff) {
+                ier = r_check3(e, b);
+                if (ier < 0) {
+                    s.status = ier;
+                    s.dead = true;
+                    continue;
+                }
+                if (ier == IDAENS_UNFINISHED) {
+                    s.irfnd = false;
+                    if (itask == IDAENS_ONE_STEP && irfndp) {
+                        s.tretlast = s.tn;
+                        s.tret = s.tn;
+                        queue_solution(s, b, s.tn, sl);
+                        s.status = IDAENS_SUCCESS;
+                        continue;
+                    }
+                } else {  // root found
+                    s.irfnd = true;
+                    s.tretlast = s.tlo;
+                    s.tret = s.tlo;
+                    s.status = IDAENS_ROOT_RETURN;
+                    continue;
+                }
+            }
+        }
         if (s.nst > 0) {
             const int istate = stop_test1(s, b, tout, itask, sl);
             if (istate != IDAENS_UNFINISHED) {
@@ -815,6 +1114,34 @@ int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hSta
     return 0;
 }
 
+int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds) {
+    if (!e || nroots < 0 || (nroots > 0 && (!comps || !thresholds))) return -1;
+    for (int i = 0; i < nroots; ++i)
+        if (comps[i] < 0 || comps[i] >= e->n) return efail(e, -2, "root function %d: component %d outside 0..%d", i, comps[i], e->n - 1);
+    for (const Sys& s : e->sys)
+        if (s.nst > 0 || s.setup_done) return efail(e, -2, "root functions must be set before the first solve call");
+    e->nrtfn = nroots;
+    e->rt_comp.assign(comps, comps + nroots);
+    e->rt_thr.assign(thresholds, thresholds + nroots);
+    e->hy.assign(e->n, 0.0);
+    e->hyp.assign(e->n, 0.0);
+    for (Sys& s : e->sys) {
+        s.glo.assign(nroots, 0.0);
+        s.ghi.assign(nroots, 0.0);
+        s.grout.assign(nroots, 0.0);
+        s.iroots.assign(nroots, 0.0);
+        s.gactive.assign(nroots, 0);  // sic: false (lib.rs:373); r_check1/3 switch them on
+    }
+    return 0;
+}
+
+int idaens_get_roots(const idaens* e, int32_t* out) {
+    if (!e || !out) return -1;
+    for (int b = 0; b < e->batch; ++b)
+        for (int i = 0; i < e->nrtfn; ++i) out[(size_t)b * e->nrtfn + i] = (int32_t)e->sys[b].iroots[i];
+    return 0;
+}
+
 int idaens_get_counter(const idaens* e, int which, int64_t* out) {
     if (!e || !out) return -1;
     for (int b = 0; b < e->batch; ++b) {
@@ -832,6 +1159,7 @@ int idaens_get_counter(const idaens* e, int which, int64_t* out) {
             case IDAENS_C_NLS_NCONVFAILS: v = s.nconvfails; break;
             case IDAENS_C_KUSED: v = s.kused; break;
             case IDAENS_C_KK: v = s.kk; break;
+            case IDAENS_C_NGE: v = s.nge; break;
             default: return -2;
         }
         out[b] = v;

@@ -34,7 +34,8 @@ HIP_SYMBOLS = [
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant",
 ]
 ENS_SYMBOLS = [
-    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_solve",
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_roots",
+    "idaens_get_roots", "idaens_solve",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
 ]
@@ -108,6 +109,8 @@ def load():
     E.idaens_last_error.restype = C.c_char_p
     E.idaens_set_max_num_steps.argtypes = [vp, C.c_long]
     E.idaens_set_max_ord.argtypes = [vp, ci]
+    E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
+    E.idaens_get_roots.argtypes = [vp, i32p]
     E.idaens_solve.argtypes = [vp, cd, ci, dp, i32p, C.c_long]
     E.idaens_get_counter.argtypes = [vp, ci, i64p]
     E.idaens_get_real.argtypes = [vp, ci, dp]
@@ -331,7 +334,7 @@ class Ctx:
 
 
 COUNTERS = {"nst": 0, "nre": 1, "nje": 2, "nsetups": 3, "nni": 4, "netf": 5, "ncfn": 6, "n_attempts": 7, "nls_nconvfails": 8,
-            "kused": 9, "kk": 10}
+            "kused": 9, "kk": 10, "nge": 11}
 REALS = {"tn": 0, "hused": 1, "hh": 2, "h0u": 3, "tolsf": 4}
 
 
@@ -361,6 +364,19 @@ class Ensemble:
 
     def set_max_num_steps(self, mxstep):
         self.E.idaens_set_max_num_steps(self.h, int(mxstep))
+
+    def set_roots(self, comps, thresholds):
+        """Root functions g_i = y[comps[i]] - thresholds[i] for every system (before the first solve)."""
+        comps, thr = _i32(comps), _f64(thresholds)
+        if self.E.idaens_set_roots(self.h, comps.size, _p(comps, i32p), _p(thr)) != 0:
+            raise IdaHipError("set_roots: %s" % (self.E.idaens_last_error(self.h) or b"").decode())
+        self.nroots = comps.size
+
+    def roots_found(self):
+        out = np.zeros((self.ctx.batch, getattr(self, "nroots", 0)), dtype=np.int32)
+        if out.size:
+            self.E.idaens_get_roots(self.h, _p(out, i32p))
+        return out
 
     def set_max_ord(self, maxord):
         if self.E.idaens_set_max_ord(self.h, int(maxord)) != 0:

@@ -268,3 +268,38 @@ def test_max_order_limit(maxord):
             assert o.solve(float(t))[0] == 0
         assert np.array_equal(o.getv("yy"), ens.yy()[s]) and np.array_equal(o.getv("yp"), ens.yp()[s])
         assert o.get("nst") == ens.counter("nst")[s] and o.get("nni") == ens.counter("nni")[s]
+
+
+def test_roberts_example_with_root_finding():
+    """examples/roberts.rs as the reference runs it: 12 outputs at 0.4 * 10^k with the two root functions (y1 - 1e-4,
+    y3 - 0.01) active. Every return of Ida::solve -- status (0 or IDA_ROOT_RETURN), t_ret, y, rootsfound -- and the
+    final counters (362 steps, 404 root-function evaluations) equal the oracle's, which is pinned on the reference's
+    own figures (tests/test_oracle_roberts.py); five copies run as one batch."""
+    import idahip
+    from idahip import problems
+    R = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "roberts_example.json")))
+    p = problems.roberts()
+    B = 5
+    p["yy0"] = np.tile(p["yy0"], (B, 1))
+    p["yp0"] = np.tile(p["yp0"], (B, 1))
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    ens.set_roots([0, 2], [0.0001, 0.01])
+    ida = O.OracleIda("roberts", 3, R["yy0"], R["yp0"], R["rtol"], R["atol"])
+    tout, iout, nroot_returns = R["tout0"], 0, 0
+    while iout < R["nout"]:
+        st_o, tret_o = ida.solve(tout)
+        st, tret = ens.solve(tout)
+        assert (st == st_o).all() and st_o >= 0
+        assert np.array_equal(tret, np.full(B, tret_o))
+        assert np.array_equal(ens.yy(), np.tile(ida.getv("yy"), (B, 1)))
+        assert np.array_equal(ens.yp(), np.tile(ida.getv("yp"), (B, 1)))
+        if st_o == 2:
+            nroot_returns += 1
+            assert np.array_equal(ens.roots_found(), np.tile(ida.getv("iroots").astype(np.int32), (B, 1)))
+        else:
+            iout += 1
+            tout *= R["tout_factor"]
+    assert nroot_returns == 2
+    c = ens.counters()
+    assert (c["nst"] == 362).all() and (c["n_attempts"] == 377).all() and (c["nge"] == 404).all()
+    assert (c["nni"] == 537).all() and (c["netf"] == 15).all()
