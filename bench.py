@@ -71,6 +71,19 @@ def profiled_traffic(cls):
     return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
 
 
+def lu_plus_solve(tim, n):
+    """The kernel-level figure north_star states its target on: one batched getrf + one getrs per system, algorithmic
+    bytes (24 N^2 + 32 N) over the device time per system of the lu class plus the newton_iter class
+    (whose kernel is the getrs with the Newton vector updates fused in)."""
+    lu, ni = tim["lu"], tim["newton_iter"]
+    if lu["systems"] == 0 or ni["systems"] == 0:
+        return None
+    us = 1e3 * (lu["ms"] / lu["systems"] + ni["ms"] / ni["systems"])
+    gbs = (24 * n * n + 32 * n) / (us * 1e-6) / 1e9
+    return {"us_per_system": round(us, 3), "GB/s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "note": "reference-exact arithmetic (unfused mul, sub) caps the getrf at 23 % of the HBM roofline (DESIGN.md section 4)"}
+
+
 def roofline(dom, d, alg_bytes, achieved, n):
     """The `roofline` object of the JSON line for the kernel class with the most device time. achieved = algorithmic bytes
     per launch / average launch duration (HIP events on the ctx stream, timed region); traffic = measured HBM bytes per
@@ -317,6 +330,7 @@ def main():
             "newton_iters_timed": iters_all,
             "roofline": roofline(dom, d, ab[dom], achieved, args.n),
             "kernel_classes_rank0": classes,
+            "lu_plus_solve": lu_plus_solve(tim, args.n),
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
         }
