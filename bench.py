@@ -33,8 +33,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(n):
+def algorithmic_bytes(n, workload="linear_dense"):
     """Per-system algorithmic HBM bytes of each kernel class (fp64 = 8 B)."""
+    if workload == "heat1d":  # three-point residual, dense Jacobian written (mostly zeros)
+        return {"newton_iter": 8 * n * n + 40 * n + 8, "sys": 56 * n, "jac": 8 * n * n, "sys_jac": 8 * n * n + 56 * n,
+                "lu": 16 * n * n + 8 * n}
     return {
         "newton_iter": 8 * n * n + 40 * n + 8,   # getrs 8N^2+24N, + neg/scale/axpy/wrms vectors 16N+8
         "sys": 16 * n * n + 40 * n,              # residual of the linear dense DAE
@@ -89,8 +92,11 @@ def roofline(dom, d, alg_bytes, achieved, n):
     per launch / average launch duration (HIP events on the ctx stream, timed region); traffic = measured HBM bytes per
     launch, i.e. the committed PMC figure per system x the systems one launch of this run processed."""
     spl = d["systems"] / max(1, d["launches"])
-    tr = profiled_traffic(dom)
+    tr = profiled_traffic(dom) if n == 512 else None  # the committed PMC passes are of the N = 512 headline workload
     extra = {}
+    if n < 0:  # not the headline workload: no committed traffic profile
+        n = -n
+        tr = None
     if dom == "lu" and d["ms"] > 0:
         # the reference-exact elimination is an unfused mul + sub per update: 2 fp64 VALU ops, ~n^3/3 updates per matrix;
         # ceiling = 256 CUs x 64 lanes x 2.4 GHz / 2 ops
@@ -215,11 +221,12 @@ def cpu_baseline(prob_small, cores):
     import oracle_lib as O
     n = prob_small["n"]
     r = O.run_ensemble(prob_small["kind"], n, prob_small["yy0"], prob_small["yp0"], prob_small["rtol"], prob_small["atol"],
-                       prob_small["touts"], A=prob_small["A"], B=prob_small["B"], c=prob_small["c"], nthreads=cores)
+                       prob_small["touts"], params=prob_small.get("params"), A=prob_small.get("A"), B=prob_small.get("B"),
+                       c=prob_small.get("c"), nthreads=cores)
     iters = int(r["counters"]["nni"].sum())
     return {"value": iters / r["seconds"], "unit": "Newton iters/s", "cores": cores, "kind": "port",
-            "sample": "%d systems of the same N=%d workload, full t=0..1 integration, %d Newton iterations in %.2f s, one std::thread per core"
-                      % (prob_small["yy0"].shape[0], n, iters, r["seconds"])}
+            "sample": "%d systems of the same N=%d workload, full t=0..%g integration, %d Newton iterations in %.2f s, one std::thread per core"
+                      % (prob_small["yy0"].shape[0], n, float(prob_small["touts"][-1]), iters, r["seconds"])}
 
 
 def main():
@@ -231,6 +238,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="systems per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("IDAHIP_BENCH_LANES", "1")),
                     help="slices of the rank's batch stepped concurrently on their own streams")
+    ap.add_argument("--workload", choices=("linear_dense", "heat1d"), default="linear_dense",
+                    help="linear_dense = config 3 (the headline, default N=512 B=4096); heat1d = config 4 (use --n 4096 --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -247,7 +256,12 @@ def main():
     t0 = time.time()
     from idahip import sharding
     first, count = sharding.shard_range(rank, world, args.batch)
-    prob = problems.linear_dense(n=args.n, batch=count, first=first, procs=procs)
+    if args.workload == "heat1d":
+        full = problems.heat1d(n=args.n, batch=args.batch * world)  # kappa_b depends on the global system id
+        prob = {k: (v[first:first + count] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
+                for k, v in full.items()}
+    else:
+        prob = problems.linear_dense(n=args.n, batch=count, first=first, procs=procs)
     t_gen = time.time() - t0
 
     cpu = None
@@ -278,7 +292,8 @@ def main():
         torch.cuda.synchronize()
 
     run = Runner(prob, local_rank, lanes=args.lanes)
-    del prob["A"], prob["B"]  # host copies no longer needed
+    prob.pop("A", None)  # host copies no longer needed
+    prob.pop("B", None)
 
     for _ in range(args.warmup):
         run.step()
@@ -298,7 +313,7 @@ def main():
     elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cpu" if rehearse else "cuda")
 
     if rank == 0:
-        ab = algorithmic_bytes(args.n)
+        ab = algorithmic_bytes(args.n, args.workload)
         dom = max(("newton_iter", "sys", "sys_jac", "jac", "lu"), key=lambda k: tim[k]["ms"])
         d = tim[dom]
         achieved = (ab[dom] * d["systems"]) / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
@@ -310,7 +325,8 @@ def main():
                 ent["GB/s"] = round(ab[k] * v["systems"] / (v["ms"] * 1e-3) / 1e9, 1)
             classes[k] = ent
         out = {
-            "metric": "Newton iters/sec (fp64), batched dense DAE N=%d B=%d" % (args.n, args.batch),
+            "metric": ("Newton iters/sec (fp64), batched dense DAE N=%d B=%d" if args.workload == "linear_dense" else
+                       "Newton iters/sec (fp64), 1-D heat equation (dense Jacobian) N=%d B=%d") % (args.n, args.batch),
             "value": iters_all / elapsed_max,
             "unit": "Newton iters/s",
             "n_gpus": world,
@@ -322,13 +338,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, "
-                                   "rtol 1e-6 atol 1e-8, t=0..1 in 10 solve calls, restart at t=1" % (args.n, args.batch),
+            "config": {"workload": ("random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, "
+                                    "rtol 1e-6 atol 1e-8, t=0..1 in 10 solve calls, restart at t=1" if args.workload == "linear_dense" else
+                                    "1-D heat equation by the method of lines, Dirichlet ends algebraic, dense Jacobian (SURVEY 8(d) "
+                                    "config 4), N=%d, B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 in 10 solve calls, restart "
+                                    "at the end") % (args.n, args.batch),
                        "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective",
                        "lanes_per_gpu": args.lanes},
             "newton_iters_timed": iters_all,
-            "roofline": roofline(dom, d, ab[dom], achieved, args.n),
+            "roofline": roofline(dom, d, ab[dom], achieved, args.n if args.workload == "linear_dense" else -args.n),
             "kernel_classes_rank0": classes,
             "lu_plus_solve": lu_plus_solve(tim, args.n),
             "cpu_baseline": cpu,
