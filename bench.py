@@ -6,12 +6,16 @@ rank per GPU. Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.json configs[2]): synthetic random linear dense index-1 DAE
 F = A y' + B y - c, N = 512, batch B = 4096 systems per GPU (distinct matrices per system, all device resident),
-rtol 1e-6, atol 1e-8, integrated from t = 0 towards t = 1 in ten Ida::solve calls of 0.1.
+rtol 1e-6, atol 1e-8, integrated from t = 0 to t = 1 with outputs every 0.1 (ten Ida::solve calls per system, handed over
+as one schedule: systems do not wait for each other at the outputs). Throughput mode: a system that has reached t = 1 is
+created anew from its initial conditions and integrates again, so the batch never drains and the measured rate is that of
+an endless stream of such integrations -- it does not depend on which rounds K and W select (the systems' first starts are
+staggered over 96 rounds and 200 untimed rounds precede the warm-up, so the batch is spread evenly over the phases of an
+integration).
 A "step" is one lock-step step attempt of the whole batch: set_coeffs -> predict -> Newton solve (residual, Jacobian +
 batched LU when the reference's rule asks for it, 1..4 triangular solves + WRMS norms) -> error test -> complete_step
-or restore, for every system that has not yet reached the current tout. When the batch reaches t = 1 the integration
-restarts from t = 0 on fresh state, so any K is well defined. Nothing is skipped: every accepted step is bit-identical
-to the CPU oracle's (tests/test_gpu_ensemble.py).
+or restore, for every one of the B systems. Nothing is skipped: every accepted step is bit-identical to the CPU
+oracle's (tests/test_gpu_ensemble.py, incl. test_streaming_restarts_reproduce_fresh_integrations).
 value = (Newton iterations of all systems on all ranks during the K timed steps) / (max over ranks of the wall time
 of those steps), inputs already resident in HBM.
 Multi-GPU (config 5): the ensemble shards embarrassingly -- rank r integrates systems [4096 r, 4096 (r+1)); no data-path
@@ -115,43 +119,40 @@ def roofline(dom, d, alg_bytes, achieved, n):
                     "binds before HBM (DESIGN.md section 4)"}
 
 
-class Lane:
-    """Continuous lock-step integration of one contiguous slice of the rank's systems, with restart at t = 1."""
+# IDAHIP_BENCH_TIME_ALL=1 (tools/profile_bench.sh): the HIP-event kernel-class timers run from the first launch of the process
+# (spin-up and warm-up included), so that kernel_classes_rank0 can be checked against a rocprofv3 kernel trace of the same
+# process; `value` is unaffected.
+TIME_ALL = os.environ.get("IDAHIP_BENCH_TIME_ALL") == "1"
 
-    def __init__(self, prob, device):
+
+class Lane:
+    """One contiguous slice of the rank's systems in throughput mode (idaens_stream): the ten Ida::solve calls of the
+    workload are one output schedule per system, a system that has reached t = 1 is created anew (Ida::new from its
+    initial conditions) and starts over at once. The batch never drains: every lock-step round works on every system,
+    each somewhere else in its integration, so the rate does not depend on which rounds are timed."""
+
+    STAGGER = 96   # the systems' first starts are spread over this many rounds (about one integration)
+    SPIN_UP = 200  # untimed rounds before the warm-up: the stagger plus one more integration
+
+    def __init__(self, prob, device, stream=None):
         import idahip
         from idahip import problems
-        self.idahip = idahip
         self.prob = prob
-        self.ctx = problems.make_ctx(prob, device=device)
-        self.ens = None
-        self.tout_i = 0
-        self.iters_done = 0
-        self._new_ensemble()
-
-    def _new_ensemble(self):
-        if self.ens is not None:
-            self.iters_done += self.ens.total_newton_iters()
-            self.ens.close()
-        self.ens = self.idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
-        self.tout_i = 0
+        self.ctx = problems.make_ctx(prob, device=device, stream=stream)
+        self.ens = idahip.Ensemble(self.ctx, prob["yy0"], prob["yp0"])
+        if TIME_ALL:
+            self.ctx.timing(True)
+            self.ctx.timing_reset()
+        self.passes = self.ens.stream(prob["touts"], self.SPIN_UP, stagger_rounds=self.STAGGER)
 
     def total_iters(self):
-        return self.iters_done + self.ens.total_newton_iters()
+        return self.ens.total_newton_iters()
 
     def step(self):
         """Exactly one lock-step round."""
-        while True:
-            before = self.ens.total_rounds()
-            status, _ = self.ens.solve(self.prob["touts"][self.tout_i], max_rounds=1)
-            if (status < 0).any():
-                raise RuntimeError("integration failed: status %s" % np.unique(status))
-            if self.ens.total_rounds() > before:
-                return
-            # every system already stood at this tout: move to the next output time (or restart)
-            self.tout_i += 1
-            if self.tout_i == len(self.prob["touts"]):
-                self._new_ensemble()
+        before = self.ens.total_rounds()
+        self.passes = self.ens.stream(self.prob["touts"], 1)
+        assert self.ens.total_rounds() == before + 1
 
 
 class Runner:
@@ -297,7 +298,8 @@ def main():
 
     for _ in range(args.warmup):
         run.step()
-    run.timing(True)
+    if not TIME_ALL:
+        run.timing(True)
     barrier()
     it0 = run.total_iters()
     t0 = time.perf_counter()
@@ -339,10 +341,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": ("random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, "
-                                    "rtol 1e-6 atol 1e-8, t=0..1 in 10 solve calls, restart at t=1" if args.workload == "linear_dense" else
+                                    "rtol 1e-6 atol 1e-8, t=0..1 with 10 outputs, every system restarts on its own when it reaches "
+                                    "t=1 (endless stream of integrations)" if args.workload == "linear_dense" else
                                     "1-D heat equation by the method of lines, Dirichlet ends algebraic, dense Jacobian (SURVEY 8(d) "
-                                    "config 4), N=%d, B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 in 10 solve calls, restart "
-                                    "at the end") % (args.n, args.batch),
+                                    "config 4), N=%d, B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 with 10 outputs, every "
+                                    "system restarts on its own at the end") % (args.n, args.batch),
                        "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective",
                        "lanes_per_gpu": args.lanes},
@@ -353,6 +356,8 @@ def main():
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
         }
+        if TIME_ALL:
+            out["kernel_classes_cover"] = "every launch of the process (spin-up, warm-up, timed steps)"
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0 over gloo -- not a scaling measurement"
         print(json.dumps(out))

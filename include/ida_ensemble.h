@@ -62,6 +62,24 @@ int idaens_get_roots(const idaens* e, int32_t* out /* [batch][nroots] */);
  * resume on the next call with the same tout). Returns 0, or < 0 on a device/ABI failure. */
 int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds);
 
+/* The same for a whole output schedule: for every system Ida::solve(touts[0]), Ida::solve(touts[1]), ... in IDA_NORMAL
+ * mode -- each return processed exactly as the reference does (stop tests, interpolation to tout) -- but a system that
+ * returns from one call enters the next at once instead of waiting for the slowest system of the batch, so the lock-step
+ * rounds stay full. A system's schedule ends early with its first status other than IDAENS_SUCCESS (root return, error).
+ * hReached[batch] (optional): number of touts returned with IDAENS_SUCCESS; hYout / hYPout (optional, [ntout][batch][n]):
+ * y, y' at every tout reached. With max_rounds > 0 the call may stop early (IDAENS_UNFINISHED); calling again with the same
+ * schedule continues it. */
+int idaens_solve_schedule(idaens* e, const double* touts, int ntout, double* hTret, int32_t* hStatus, int32_t* hReached,
+                          double* hYout, double* hYPout, long max_rounds);
+
+/* Throughput mode: the schedule as above, and a system that has returned from its last tout is created anew from its
+ * initial conditions (Ida::new) and starts the schedule again at once -- the batch never drains, every lock-step round
+ * works on every system, each somewhere else in its integration. Runs max_rounds rounds; call again to continue.
+ * stagger_rounds > 0 (first call only): system b enters at round b * stagger_rounds / batch, which spreads the systems
+ * evenly over the phases of an integration from the start. passes_done (optional): integrations completed since the
+ * ensemble was created. Per-system counters restart with the system; idaens_total_newton_iters keeps the total. */
+int idaens_stream(idaens* e, const double* touts, int ntout, long max_rounds, long stagger_rounds, int64_t* passes_done);
+
 /* getters (src/ida_io.rs:11-117), arrays of length batch */
 enum {
     IDAENS_C_NST = 0, IDAENS_C_NRE = 1, IDAENS_C_NJE = 2, IDAENS_C_NSETUPS = 3, IDAENS_C_NNI = 4, IDAENS_C_NETF = 5,

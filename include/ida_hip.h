@@ -134,6 +134,12 @@ int idahip_complete_step(idahip_ctx* ctx, const int32_t* hKused, const double* h
 int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCvals, const double* hDvals,
                         const int32_t* hIdx, int nsys);
 
+/* Ida::new again for some systems of a running ensemble (src/lib.rs:278-405: phi[0] = yy = y0, phi[1] = yp = y0'):
+ * idahip_snapshot_initial keeps a device copy of the current phi[0], phi[1] of every system (call it right after the
+ * initial conditions were uploaded); idahip_restore_initial puts the listed systems back to it. */
+int idahip_snapshot_initial(idahip_ctx* ctx);
+int idahip_restore_initial(idahip_ctx* ctx, const int32_t* hIdx, int nsys);
+
 /* LU implementation choice (all bit-identical to dense_get_rf): 3 = default: column-major work
  * matrix, 64-column super-panels built from two 32-column panels with two rows per lane, rank-64 trailing update in
  * wave-private 16-row strips; 2 = the same with one row per lane in the panel kernel; 0 = 32-column panels and rank-32

@@ -58,6 +58,7 @@ struct idahip_ctx {
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr;
     double* lu_l11 = nullptr;
+    double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     int lu_variant = 3;  // 3: 64-column super-panels, two rows per lane in the panel kernel (lu_kernels.hpp, default)
                          // 2: the same with one row per lane; 0: 32-column panels + rank-32 trailing kernel
                          // 1: row-major work matrix, 16-column sub-panels, rank-64 trailing update (lu_rm.hpp)

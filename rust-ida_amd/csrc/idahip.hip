@@ -125,7 +125,8 @@ int idahip_destroy(idahip_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v};
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->ic_yp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < NSLOT; ++i) {
@@ -703,6 +704,38 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
         KTimer kt(c, IDAHIP_K_VECTOR, nsys);
         hipLaunchKernelGGL(get_solution_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_ko, d_cv, d_dv);
         if ((rc = post_launch(c, "get_solution"))) return rc;
+    }
+    return ap.finish_async();
+}
+
+int idahip_snapshot_initial(idahip_ctx* c) {
+    if (!c) return -1;
+    const size_t bn = (size_t)c->batch * c->n;
+    int rc = 0;
+    if (!c->ic_y) {
+        rc |= dalloc(c, &c->ic_y, bn);
+        rc |= dalloc(c, &c->ic_yp, bn);
+        if (rc) return fail(c, -4, "device allocation of the initial-condition copies failed");
+    }
+    IDAHIP_HIP(c, hipMemcpyAsync(c->ic_y, c->phi, bn * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(c->ic_yp, c->phi + bn, bn * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!c->ic_y) return fail(c, -2, "idahip_restore_initial before idahip_snapshot_initial");
+    if (nsys == 0) return 0;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(restore_initial_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), (const double*)c->ic_y,
+                           (const double*)c->ic_yp, d_idx);
+        if ((rc = post_launch(c, "restore_initial"))) return rc;
     }
     return ap.finish_async();
 }

@@ -194,4 +194,18 @@ __global__ __launch_bounds__(256) void get_solution_kernel(VecState s, const int
     }
 }
 
+// Ida::new for the listed systems (lib.rs:291-293, ida_nls.rs:83-84): phi[0] = yy = y0, phi[1] = yp = y0'
+__global__ __launch_bounds__(256) void restore_initial_kernel(VecState s, const double* __restrict__ icy, const double* __restrict__ icyp,
+                                                              const int* __restrict__ idx) {
+    const int b = idx[blockIdx.x];
+    const long vb = (long)b * s.n;
+    for (int i = threadIdx.x; i < s.n; i += 256) {
+        const double y = icy[vb + i], yp = icyp[vb + i];
+        s.phi[vb + i] = y;
+        s.phi[s.phistride + vb + i] = yp;
+        s.yy[vb + i] = y;
+        s.yp[vb + i] = yp;
+    }
+}
+
 }  // namespace idahip

@@ -77,6 +77,8 @@ struct Sys {
     int status = 0;
     double tret = 0.0;
     bool dead = false;  // a fatal IdaError was returned: later solve calls report it again
+    double tout_cur = 0.0;  // the tout of the Ida::solve call this system is inside
+    int sched_i = 0;        // index of that tout in the caller's schedule (idaens_solve: always 0)
     // --- root finding (src/lib.rs:225-244, src/impl_r_check.rs); the vectors have nrtfn entries when roots are enabled
     std::vector<double> glo, ghi, grout, iroots;
     std::vector<uint8_t> gactive;
@@ -100,6 +102,11 @@ struct idaens {
     int64_t total_rounds = 0;
     int trace_sys = -1;
     std::vector<double> trace;
+    bool sched_unfinished = false;  // the last idaens_solve_schedule call stopped at its round limit
+    double t0 = 0.0;                // every system starts at tn = t0 (Sys default)
+    int64_t retired_iters = 0, passes = 0;  // idaens_stream: Newton iterations / integrations of systems already restarted
+    bool have_ic = false, streaming = false;
+    std::vector<int64_t> start_round;  // idaens_stream with a stagger: the round at which each system first enters
     // root functions g_i(t, y, y') = y[rt_comp[i]] - rt_thr[i] (the form of the reference's Roberts example,
     // src/sample_problems/roberts.rs: g0 = y0 - 1e-4, g1 = y2 - 0.01); nrtfn == 0: no root finding
     int nrtfn = 0;
@@ -729,8 +736,43 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
     return 0;
 }
 
+// ---------------------------------------------------------------- one idaens_solve / idaens_solve_schedule call
+// A schedule touts[0..ntout) means: for every system, Ida::solve(touts[0]), then Ida::solve(touts[1]), ... -- but a
+// system that returns from one call enters the next at once instead of waiting for the slowest system of the batch, so
+// the lock-step rounds stay full. Each return is processed exactly as the reference does (stop tests, interpolation
+// to tout).
+struct SolveCall {
+    const double* touts = nullptr;
+    int ntout = 1;
+    int itask = IDAENS_NORMAL;
+    SolList sl;                                 // interpolations queued for the device
+    std::vector<std::pair<int, int>> reached;   // (system, schedule index) whose output is in sl
+    double *hYout = nullptr, *hYPout = nullptr; // optional [ntout][batch][n]
+    int32_t* hReached = nullptr;                // optional [batch]: returns with IDAENS_SUCCESS so far
+    bool recycle = false;                       // idaens_stream: a system that finished the schedule starts over at once
+};
+
+// run the queued interpolations, hand the outputs of the touts reached since the last call to the caller
+int emit_outputs(idaens* e, SolveCall& C) {
+    int rc = flush_solutions(e, C.sl);
+    if (rc) return rc;
+    if (C.hYout || C.hYPout) {
+        const size_t n = e->n, bn = (size_t)e->batch * n;
+        for (const auto& r : C.reached) {
+            if (C.hYout) ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YY, r.first, 1, C.hYout + r.second * bn + r.first * n));
+            if (C.hYPout) ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YP, r.first, 1, C.hYPout + r.second * bn + r.first * n));
+        }
+    }
+    C.reached.clear();
+    return 0;
+}
+
 // ---------------------------------------------------------------- one lock-step round over `act`
-int attempt_round(idaens* e, std::vector<int32_t>& act, double tout, int itask, SolList& sl) {
+int continue_schedule(idaens* e, SolveCall& C, int b);
+
+int attempt_round(idaens* e, std::vector<int32_t>& act, SolveCall& C) {
+    SolList& sl = C.sl;
+    const int itask = C.itask;
     std::vector<Sys>& S = e->sys;
     const int na = (int)act.size();
     // --- step() prologue + set_coeffs + tn += hh (lib.rs:619-653)
@@ -879,10 +921,13 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, double tout, int itask, 
                     continue;
                 }
             }
-            const int istate = stop_test2(s, b, tout, itask, sl);
+            const int istate = stop_test2(s, b, s.tout_cur, itask, sl);
             if (istate != IDAENS_UNFINISHED) {
                 s.status = istate;
                 s.ph = PH_IDLE;
+                const int cs = continue_schedule(e, C, b);  // the next tout of the schedule, if there is one
+                if (cs < 0) return cs;
+                if (cs == 1) next.push_back(b);
             } else {
                 next.push_back(b);
             }
@@ -912,6 +957,7 @@ int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const doubl
         delete e;
         return rc;
     }
+    e->have_ic = idahip_snapshot_initial(ctx) == 0;  // for idaens_stream's restarts; costs two batch-sized vectors
     *out = e;
     return 0;
 }
@@ -934,123 +980,178 @@ int idaens_set_max_ord(idaens* e, int maxord) {
     return 0;
 }
 
-int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds) {
-    if (!e || !hTret || !hStatus) return -1;
-    const double eps = std::numeric_limits<double>::epsilon();
-    std::vector<Sys>& S = e->sys;
-    SolList sl;
-    std::vector<int32_t> act;
+}  // extern "C"
 
-    // ---- first-call block for systems that have not started (impl_solve.rs:84-173)
-    {
-        std::vector<int32_t> fresh;
-        for (int b = 0; b < e->batch; ++b)
-            if (S[b].ph == PH_IDLE && S[b].nst == 0 && !S[b].setup_done && !S[b].dead) fresh.push_back(b);
-        if (!fresh.empty()) {
-            // initial_setup's ewt_set(phi[0]) (lib.rs:537-545), ||phi[1]|| for the h0 heuristic (impl_solve.rs:122-126)
-            // and ||phi[0]|| for the first tolsf test (impl_solve.rs:289-295)
-            std::vector<double> ypnorm(fresh.size()), p0nrm(fresh.size());
-            ENS_CALL(e, idahip_init_first(e->ctx, ypnorm.data(), p0nrm.data(), fresh.data(), (int)fresh.size()));
-            std::vector<int32_t> ok;
-            std::vector<double> fac;
-            for (size_t q = 0; q < fresh.size(); ++q) {
-                Sys& s = S[fresh[q]];
-                const double tdist = std::fabs(tout - s.tn);
-                const double troundoff = 2.0 * eps * (std::fabs(s.tn) + std::fabs(tout));
-                if (tdist == 0.0 || tdist < troundoff) {
-                    s.status = IDAENS_ILL_INPUT;  // "tout too close to t0 to start integration"
-                    s.tret = s.tn;
-                    continue;
-                }
-                s.setup_done = true;
-                s.hh = s.hin;
-                if (s.hh == 0.0) {
-                    s.hh = 0.001 * tdist;
-                    if (ypnorm[q] > 2.0 / s.hh) s.hh = 0.5 / ypnorm[q];  // Q7 kept (impl_solve.rs:127)
-                    if (tout < s.tn) s.hh = -s.hh;
-                }
-                const double rh = std::fabs(s.hh) * e->hmax_inv;
-                if (rh > 1.0) s.hh /= rh;
-                s.h0u = s.hh;
-                s.kk = 0;
-                s.kused = 0;
-                s.eps_newt = e->epcon;
-                s.toldel = 0.0001 * s.eps_newt;
-                s.phi0nrm = p0nrm[q];
-                ok.push_back(fresh[q]);
-                fac.push_back(s.hh);
-            }
-            if (e->nrtfn > 0)
-                for (int b : ok) {  // impl_solve.rs:157-159
-                    const int rc1 = r_check1(e, b);
-                    if (rc1) return rc1;
-                }
-            if (!ok.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, fac.data(), ok.data(), (int)ok.size()));  // phi[1] = hh*y'
-        }
-    }
+namespace {
 
-    // ---- per-system entry: stop tests for started systems, then collect who steps (impl_solve.rs:179-241)
-    for (int b = 0; b < e->batch; ++b) {
-        Sys& s = S[b];
-        if (s.ph != PH_IDLE) {  // left mid-flight by a round limit: resume
-            act.push_back(b);
-            continue;
+// Entry of one Ida::solve(s.tout_cur) call for a system that is between calls (impl_solve.rs:179-241): root checks and
+// stop tests. Returns IDAENS_UNFINISHED when the system has to step, else the status this call returns with (tret set).
+int enter_call(idaens* e, SolveCall& C, int b) {
+    Sys& s = e->sys[b];
+    SolList& sl = C.sl;
+    const int itask = C.itask;
+    const double tout = s.tout_cur;
+    s.nstloc = 0;
+    if (itask == IDAENS_NORMAL) s.toutc = tout;
+    s.taskc = itask;
+    if (s.nst > 0 && e->nrtfn > 0) {
+        const double eps_ = std::numeric_limits<double>::epsilon();
+        const bool irfndp = s.irfnd;
+        int ier = r_check2(e, b);
+        if (ier < 0) {
+            s.dead = true;
+            return ier;
         }
-        if (s.dead || !s.setup_done) continue;  // earlier fatal error / ILL_INPUT at the first call: status is sticky
-        s.nstloc = 0;
-        if (itask == IDAENS_NORMAL) s.toutc = tout;
-        s.taskc = itask;
-        if (s.nst > 0 && e->nrtfn > 0) {
-            const double eps_ = std::numeric_limits<double>::epsilon();
-            const bool irfndp = s.irfnd;
-            int ier = r_check2(e, b);
+        if (ier == IDAENS_ROOT_RETURN) {
+            s.tretlast = s.tlo;
+            s.tret = s.tlo;
+            return IDAENS_ROOT_RETURN;
+        }
+        const double troundoff = (std::fabs(s.tn) + std::fabs(s.hh)) * eps_ * 100.0;
+        if (std::fabs(s.tn - s.tretlast) > troundoff) {
+            ier = r_check3(e, b);
             if (ier < 0) {
-                s.status = ier;
                 s.dead = true;
-                continue;
+                return ier;
             }
-            if (ier == IDAENS_ROOT_RETURN) {
+            if (ier == IDAENS_UNFINISHED) {
+                s.irfnd = false;
+                if (itask == IDAENS_ONE_STEP && irfndp) {
+                    s.tretlast = s.tn;
+                    s.tret = s.tn;
+                    queue_solution(s, b, s.tn, sl);
+                    return IDAENS_SUCCESS;
+                }
+            } else {  // root found
+                s.irfnd = true;
                 s.tretlast = s.tlo;
                 s.tret = s.tlo;
-                s.status = IDAENS_ROOT_RETURN;
-                continue;
+                return IDAENS_ROOT_RETURN;
             }
-            const double troundoff = (std::fabs(s.tn) + std::fabs(s.hh)) * eps_ * 100.0;
-            if (std::fabs(s.tn - s.tretlast) > troundoff) {
-                ier = r_check3(e, b);
-                if (ier < 0) {
-                    s.status = ier;
-                    s.dead = true;
-                    continue;
-                }
-                if (ier == IDAENS_UNFINISHED) {
-                    s.irfnd = false;
-                    if (itask == IDAENS_ONE_STEP && irfndp) {
-                        s.tretlast = s.tn;
+        }
+    }
+    if (s.nst > 0) {
+        const int istate = stop_test1(s, b, tout, itask, sl);
+        if (istate != IDAENS_UNFINISHED) {
+            if (istate < 0) s.dead = true;
+            return istate;
+        }
+    }
+    return IDAENS_UNFINISHED;
+}
+
+// A system's call has just returned (s.status set, phase idle). With IDAENS_SUCCESS and touts left in the schedule it
+// enters the next call at once. Returns 1 when the system is stepping again, 0 when it is done for this call, < 0 on a
+// device failure.
+int continue_schedule(idaens* e, SolveCall& C, int b) {
+    Sys& s = e->sys[b];
+    for (;;) {
+        if (s.status == IDAENS_SUCCESS) C.reached.push_back({b, s.sched_i});
+        if (s.status != IDAENS_SUCCESS || s.sched_i + 1 >= C.ntout) return 0;
+        s.sched_i += 1;
+        s.tout_cur = C.touts[s.sched_i];
+        // the next call may interpolate again for this system (tn already past the next tout), or bracket a root through
+        // yy/yp: the output of the call that just returned has to be out of the way first
+        if (e->nrtfn > 0 || (s.tn - s.tout_cur) * s.hh >= 0.0) {
+            const int rc = emit_outputs(e, C);
+            if (rc) return rc;
+        }
+        const int ist = enter_call(e, C, b);
+        if (ist == IDAENS_UNFINISHED) {
+            s.ph = PH_LOOP_TOP;
+            return 1;
+        }
+        s.status = ist;
+    }
+}
+
+int solve_core(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    std::vector<Sys>& S = e->sys;
+    SolList& sl = C.sl;
+    const double tout = C.touts[0];  // the first call's tout sizes the initial step (impl_solve.rs:104-131)
+    std::vector<int32_t> act;
+    const bool resume = C.ntout > 1 && e->sched_unfinished;  // continuing a round-limited schedule call
+
+    // (re)enter the schedule with the idle systems `cand`: first-call block for those that have not started, then the
+    // entry of their first Ida::solve call; whoever has to step is appended to `act`
+    auto start_systems = [&](const std::vector<int32_t>& cand) -> int {
+    // ---- first-call block for systems that have not started (impl_solve.rs:84-173)
+        {
+            std::vector<int32_t> fresh;
+            for (int b : cand)
+                if (S[b].ph == PH_IDLE && S[b].nst == 0 && !S[b].setup_done && !S[b].dead) fresh.push_back(b);
+            if (!fresh.empty()) {
+                // initial_setup's ewt_set(phi[0]) (lib.rs:537-545), ||phi[1]|| for the h0 heuristic (impl_solve.rs:122-126)
+                // and ||phi[0]|| for the first tolsf test (impl_solve.rs:289-295)
+                std::vector<double> ypnorm(fresh.size()), p0nrm(fresh.size());
+                ENS_CALL(e, idahip_init_first(e->ctx, ypnorm.data(), p0nrm.data(), fresh.data(), (int)fresh.size()));
+                std::vector<int32_t> ok;
+                std::vector<double> fac;
+                for (size_t q = 0; q < fresh.size(); ++q) {
+                    Sys& s = S[fresh[q]];
+                    const double tdist = std::fabs(tout - s.tn);
+                    const double troundoff = 2.0 * eps * (std::fabs(s.tn) + std::fabs(tout));
+                    if (tdist == 0.0 || tdist < troundoff) {
+                        s.status = IDAENS_ILL_INPUT;  // "tout too close to t0 to start integration"
                         s.tret = s.tn;
-                        queue_solution(s, b, s.tn, sl);
-                        s.status = IDAENS_SUCCESS;
                         continue;
                     }
-                } else {  // root found
-                    s.irfnd = true;
-                    s.tretlast = s.tlo;
-                    s.tret = s.tlo;
-                    s.status = IDAENS_ROOT_RETURN;
-                    continue;
+                    s.setup_done = true;
+                    s.hh = s.hin;
+                    if (s.hh == 0.0) {
+                        s.hh = 0.001 * tdist;
+                        if (ypnorm[q] > 2.0 / s.hh) s.hh = 0.5 / ypnorm[q];  // Q7 kept (impl_solve.rs:127)
+                        if (tout < s.tn) s.hh = -s.hh;
+                    }
+                    const double rh = std::fabs(s.hh) * e->hmax_inv;
+                    if (rh > 1.0) s.hh /= rh;
+                    s.h0u = s.hh;
+                    s.kk = 0;
+                    s.kused = 0;
+                    s.eps_newt = e->epcon;
+                    s.toldel = 0.0001 * s.eps_newt;
+                    s.phi0nrm = p0nrm[q];
+                    ok.push_back(fresh[q]);
+                    fac.push_back(s.hh);
                 }
+                if (e->nrtfn > 0)
+                    for (int b : ok) {  // impl_solve.rs:157-159
+                        const int rc1 = r_check1(e, b);
+                        if (rc1) return rc1;
+                    }
+                if (!ok.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, fac.data(), ok.data(), (int)ok.size()));  // phi[1] = hh*y'
             }
         }
-        if (s.nst > 0) {
-            const int istate = stop_test1(s, b, tout, itask, sl);
-            if (istate != IDAENS_UNFINISHED) {
-                s.status = istate;
-                if (istate < 0) s.dead = true;
+
+        // ---- per-system entry: stop tests for started systems, then collect who steps (impl_solve.rs:179-241)
+        for (int b : cand) {
+            Sys& s = S[b];
+            if (s.dead || !s.setup_done) continue;  // earlier fatal error / ILL_INPUT at the first call: status is sticky
+            s.sched_i = 0;
+            s.tout_cur = C.touts[0];
+            const int ist = enter_call(e, C, b);
+            if (ist == IDAENS_UNFINISHED) {
+                s.ph = PH_LOOP_TOP;
+                act.push_back(b);
                 continue;
             }
+            s.status = ist;
+            const int cs = continue_schedule(e, C, b);
+            if (cs < 0) return cs;
+            if (cs == 1) act.push_back(b);
         }
-        s.ph = PH_LOOP_TOP;
-        act.push_back(b);
+        return 0;
+    };
+    {
+        std::vector<int32_t> cand;
+        for (int b = 0; b < e->batch; ++b) {
+            if (S[b].ph != PH_IDLE) act.push_back(b);  // left mid-flight by a round limit: resume
+            else if (C.recycle && !e->start_round.empty() && e->start_round[b] > e->total_rounds) continue;  // staggered start
+            else if (!resume) cand.push_back(b);       // (resume: idle systems finished in an earlier slice of the call)
+        }
+        const int rc0 = start_systems(cand);
+        if (rc0) return rc0;
     }
 
     // ---- main loop
@@ -1094,24 +1195,109 @@ int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hSta
         }
         act.swap(go);
         if (act.empty()) break;
-        int rc = attempt_round(e, act, tout, itask, sl);
+        int rc = attempt_round(e, act, C);
         if (rc) return rc;
         rounds += 1;
         e->total_rounds += 1;
+        if (C.ntout > 1 || C.recycle) {  // outputs of the touts reached in this round, before the next round steps on
+            rc = emit_outputs(e, C);
+            if (rc) return rc;
+        }
+        if (C.recycle) {  // Ida::new again for the systems that finished their schedule in this round
+            std::vector<int32_t> again;
+            for (int b = 0; b < e->batch; ++b) {
+                Sys& s = S[b];
+                if (s.ph == PH_IDLE && !s.dead && s.setup_done && s.status == IDAENS_SUCCESS && s.sched_i == C.ntout - 1 && s.nst > 0) {
+                    e->retired_iters += s.niters;
+                    e->passes += 1;
+                    s = Sys();
+                    s.tn = e->t0;
+                    again.push_back(b);
+                }
+            }
+            if (!again.empty()) {
+                ENS_CALL(e, idahip_restore_initial(e->ctx, again.data(), (int)again.size()));
+                rc = start_systems(again);
+                if (rc) return rc;
+            }
+            if (!e->start_round.empty()) {  // staggered start: the systems whose turn it is now
+                std::vector<int32_t> late;
+                for (int b = 0; b < e->batch; ++b)
+                    if (e->start_round[b] == e->total_rounds && S[b].ph == PH_IDLE && S[b].nst == 0 && !S[b].setup_done) late.push_back(b);
+                if (!late.empty()) {
+                    rc = start_systems(late);
+                    if (rc) return rc;
+                }
+            }
+        }
     }
-    int rc = flush_solutions(e, sl);
+    int rc = emit_outputs(e, C);
     if (rc) return rc;
+    bool unfinished = false;
     for (int b = 0; b < e->batch; ++b) {
         Sys& s = S[b];
+        if (C.hReached) C.hReached[b] = s.sched_i + ((s.ph == PH_IDLE && s.status == IDAENS_SUCCESS) ? 1 : 0);
         if (s.ph != PH_IDLE) {
             hStatus[b] = IDAENS_UNFINISHED;
             hTret[b] = s.tn;
+            unfinished = true;
         } else {
             hStatus[b] = s.status;
             hTret[b] = s.tret;
         }
     }
+    e->sched_unfinished = C.ntout > 1 && unfinished;
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds) {
+    if (!e || !hTret || !hStatus) return -1;
+    SolveCall C;
+    C.touts = &tout;
+    C.ntout = 1;
+    C.itask = itask;
+    return solve_core(e, C, hTret, hStatus, max_rounds);
+}
+
+int idaens_stream(idaens* e, const double* touts, int ntout, long max_rounds, long stagger_rounds, int64_t* passes_done) {
+    if (!e || !touts || ntout < 1 || max_rounds < 1 || stagger_rounds < 0) return -1;
+    if (!e->streaming && stagger_rounds > 0) {  // first call: system b enters at round b * stagger / batch
+        e->start_round.resize(e->batch);
+        for (int b = 0; b < e->batch; ++b) e->start_round[b] = e->total_rounds + (int64_t)b * stagger_rounds / e->batch;
+    }
+    if (e->nrtfn > 0) return efail(e, -2, "idaens_stream does not combine with root finding");
+    if (!e->have_ic) return efail(e, -2, "no snapshot of the initial conditions (idaens_create failed to take it)");
+    SolveCall C;
+    C.touts = touts;
+    C.ntout = ntout;
+    C.itask = IDAENS_NORMAL;
+    C.recycle = true;
+    std::vector<double> tret(e->batch);
+    std::vector<int32_t> status(e->batch);
+    e->sched_unfinished = e->total_rounds > 0 && e->streaming;  // later slices continue the systems in flight
+    e->streaming = true;
+    const int rc = solve_core(e, C, tret.data(), status.data(), max_rounds);
+    if (passes_done) *passes_done = e->passes;
+    for (int b = 0; b < e->batch; ++b)
+        if (status[b] < 0) return efail(e, -5, "system %d failed with status %d while streaming", b, status[b]);
+    return rc;
+}
+
+int idaens_solve_schedule(idaens* e, const double* touts, int ntout, double* hTret, int32_t* hStatus, int32_t* hReached,
+                          double* hYout, double* hYPout, long max_rounds) {
+    if (!e || !touts || ntout < 1 || !hTret || !hStatus) return -1;
+    SolveCall C;
+    C.touts = touts;
+    C.ntout = ntout;
+    C.itask = IDAENS_NORMAL;
+    C.hReached = hReached;
+    C.hYout = hYout;
+    C.hYPout = hYPout;
+    return solve_core(e, C, hTret, hStatus, max_rounds);
 }
 
 int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds) {
@@ -1196,8 +1382,10 @@ int idaens_get_yp(idaens* e, double* hYP) {
 
 int64_t idaens_total_newton_iters(const idaens* e) {
     int64_t t = 0;
-    if (e)
+    if (e) {
+        t = e->retired_iters;
         for (const Sys& s : e->sys) t += s.niters;
+    }
     return t;
 }
 int64_t idaens_total_rounds(const idaens* e) { return e ? e->total_rounds : 0; }

@@ -31,11 +31,12 @@ HIP_SYMBOLS = [
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution",
-    "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant",
+    "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
+    "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_roots",
-    "idaens_get_roots", "idaens_solve",
+    "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
 ]
@@ -112,6 +113,8 @@ def load():
     E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
     E.idaens_get_roots.argtypes = [vp, i32p]
     E.idaens_solve.argtypes = [vp, cd, ci, dp, i32p, C.c_long]
+    E.idaens_solve_schedule.argtypes = [vp, dp, ci, dp, i32p, i32p, dp, dp, C.c_long]
+    E.idaens_stream.argtypes = [vp, dp, ci, C.c_long, C.c_long, i64p]
     E.idaens_get_counter.argtypes = [vp, ci, i64p]
     E.idaens_get_real.argtypes = [vp, ci, dp]
     E.idaens_get_yy.argtypes = [vp, dp]
@@ -389,6 +392,33 @@ class Ensemble:
         if rc < 0:
             raise IdaHipError("idaens_solve failed (%d): %s" % (rc, self.E.idaens_last_error(self.h).decode()))
         return status, tret
+
+    def solve_schedule(self, touts, max_rounds=0, outputs=False):
+        """Ida::solve(touts[0]), solve(touts[1]), ... per system without the systems waiting for each other.
+        -> (status, tret, reached[, yy_out, yp_out]) with yy_out/yp_out of shape (ntout, batch, n) when outputs is set."""
+        touts = _f64(np.atleast_1d(touts))
+        B, n = self.ctx.batch, self.ctx.n
+        tret = np.zeros(B)
+        status = np.zeros(B, dtype=np.int32)
+        reached = np.zeros(B, dtype=np.int32)
+        yo = np.full((touts.size, B, n), np.nan) if outputs else None
+        ypo = np.full((touts.size, B, n), np.nan) if outputs else None
+        rc = self.E.idaens_solve_schedule(self.h, _p(touts), touts.size, _p(tret), _p(status, i32p), _p(reached, i32p),
+                                          _p(yo) if outputs else None, _p(ypo) if outputs else None, int(max_rounds))
+        if rc < 0:
+            raise IdaHipError("idaens_solve_schedule failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+        return (status, tret, reached, yo, ypo) if outputs else (status, tret, reached)
+
+    def stream(self, touts, max_rounds, stagger_rounds=0):
+        """Throughput mode: max_rounds lock-step rounds of the schedule with finished systems restarting at once
+        (stagger_rounds: spread the first starts over that many rounds). -> integrations completed since the ensemble
+        was created."""
+        touts = _f64(np.atleast_1d(touts))
+        done = C.c_int64(0)
+        rc = self.E.idaens_stream(self.h, _p(touts), touts.size, int(max_rounds), int(stagger_rounds), C.byref(done))
+        if rc < 0:
+            raise IdaHipError("idaens_stream failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+        return done.value
 
     def counter(self, name):
         out = np.zeros(self.ctx.batch, dtype=np.int64)

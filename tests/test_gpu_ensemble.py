@@ -303,3 +303,68 @@ def test_roberts_example_with_root_finding():
     c = ens.counters()
     assert (c["nst"] == 362).all() and (c["n_attempts"] == 377).all() and (c["nge"] == 404).all()
     assert (c["nni"] == 537).all() and (c["netf"] == 15).all()
+
+
+@pytest.mark.parametrize("kind", ["linear_dense", "lorenz63", "heat1d"])
+def test_output_schedule_equals_sequential_solve_calls(kind):
+    """idaens_solve_schedule: every system runs solve(t1), solve(t2), ... without waiting for the others. The output at
+    every tout, the final state and every counter equal the oracle's sequential calls; far fewer lock-step rounds."""
+    import idahip
+    from idahip import problems
+    p = {"linear_dense": lambda: problems.linear_dense(n=40, batch=9), "lorenz63": lambda: problems.lorenz63(batch=300),
+         "heat1d": lambda: problems.heat1d(n=40, batch=4)}[kind]()
+    touts = p["touts"][:10]
+    ref = run_oracle(p, touts=touts)
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    status, tret, reached, yo, ypo = ens.solve_schedule(touts, outputs=True)
+    assert (status == 0).all() and (reached == len(touts)).all() and np.array_equal(tret, np.full_like(tret, touts[-1]))
+    assert np.array_equal(yo, ref["yy"]) and np.array_equal(ypo, ref["yp"])
+    assert np.array_equal(ens.yy(), ref["yy"][-1]) and np.array_equal(ens.yp(), ref["yp"][-1])
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    # the same through solve() call by call costs more rounds (every call waits for its slowest system)
+    seq = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    for t in touts:
+        seq.solve(float(t))
+    assert np.array_equal(seq.yy(), ens.yy())
+    assert ens.total_rounds() <= seq.total_rounds()
+    # sliced by a round limit it continues where it stopped
+    sl = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    while True:
+        st, _, rc = sl.solve_schedule(touts, max_rounds=2)
+        if (st != 99).all():
+            break
+    assert (st == 0).all() and (rc == len(touts)).all()
+    assert np.array_equal(sl.yy(), ens.yy()) and np.array_equal(sl.counter("nni"), ens.counter("nni"))
+    assert sl.total_rounds() == ens.total_rounds()
+
+
+def test_streaming_restarts_reproduce_fresh_integrations():
+    """idaens_stream: systems that finish t = 1 are created anew and start over while the others keep going. Whatever
+    pass a system is in, its accepted steps are those of a fresh integration: after any number of rounds its (nst, t_n,
+    h_used, order) is exactly the oracle's nst-th step."""
+    import idahip
+    from idahip import problems
+    n, B = 24, 12
+    p = problems.linear_dense(n=n, batch=B)
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    steps = []
+    for s in range(B):
+        o = O.OracleIda("linear_dense", n, p["yy0"][s], p["yp0"][s], p["rtol"], p["atol"], A=p["A"][s], B=p["B"][s], c=p["c"][s])
+        O.lib().oracle_ida_record_steps(o.h, 1)
+        for t in p["touts"]:
+            assert o.solve(float(t))[0] == 0
+        steps.append(o.recorded_steps())
+    full_nni = run_oracle(p)["counters"]["nni"]
+    rounds, passes = 0, 0
+    while passes < 3 * B:
+        passes = ens.stream(p["touts"], 7)
+        rounds += 7
+        nst, tn, hu, ku = ens.counter("nst"), ens.real("tn"), ens.real("hused"), ens.counter("kused")
+        for s in range(B):
+            if nst[s] > 0:
+                assert np.array_equal(steps[s][nst[s] - 1, :3], [tn[s], hu[s], float(ku[s])]), (s, nst[s])
+    assert ens.total_rounds() == rounds
+    # every completed integration contributed its full Newton count, the running ones their partial counts
+    assert ens.total_newton_iters() >= 3 * full_nni.min() * B // 2
