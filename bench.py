@@ -156,64 +156,28 @@ class Lane:
 
 
 class Runner:
-    """The rank's batch as `lanes` contiguous slices, each with its own device context and stream, stepped together: a
-    step is one lock-step round of every slice, i.e. of the whole batch. With lanes > 1 the slices run from their own
-    host threads (the C ABI releases the GIL), so the host-side control of one slice overlaps the device work of the
-    others, and the latency-bound panel kernels of one slice overlap the throughput-bound kernels of another."""
+    """The rank's whole batch as one ensemble on one device context and stream. (Two or four slices stepped concurrently
+    from their own host threads were tried: +1.5 % at best -- the kernels of the slices slow each other down.)"""
 
-    def __init__(self, prob, device, lanes=1):
-        import threading
-        batch = prob["yy0"].shape[0]
-        edges = [batch * i // lanes for i in range(lanes + 1)]
-        self.lanes = []
-        for i in range(lanes):
-            lo, hi = edges[i], edges[i + 1]
-            sub = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == batch else v) for k, v in prob.items()}
-            self.lanes.append(Lane(sub, device))
-        self._threading = threading
+    def __init__(self, prob, device):
+        self.lane = Lane(prob, device)
 
     def total_iters(self):
-        return sum(l.total_iters() for l in self.lanes)
+        return self.lane.total_iters()
 
     def step(self):
-        if len(self.lanes) == 1:
-            self.lanes[0].step()
-            return
-        errs = []
-
-        def run(l):
-            try:
-                l.step()
-            except Exception as e:  # noqa: BLE001 -- re-raised on the caller's thread
-                errs.append(e)
-        th = [self._threading.Thread(target=run, args=(l,)) for l in self.lanes]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if errs:
-            raise errs[0]
+        self.lane.step()
 
     def sync(self):
-        for l in self.lanes:
-            l.ctx._chk(l.ctx.H.idahip_sync(l.ctx.h), "sync")
+        c = self.lane.ctx
+        c._chk(c.H.idahip_sync(c.h), "sync")
 
     def timing(self, on):
-        for l in self.lanes:
-            l.ctx.timing(on)
-            l.ctx.timing_reset()
+        self.lane.ctx.timing(on)
+        self.lane.ctx.timing_reset()
 
     def timing_get(self):
-        tot = None
-        for l in self.lanes:
-            t = l.ctx.timing_get()
-            if tot is None:
-                tot = t
-            else:
-                for k, v in t.items():
-                    for kk in v:
-                        tot[k][kk] += v[kk]
-        return tot
+        return self.lane.ctx.timing_get()
 
 
 def cpu_baseline(prob_small, cores):
@@ -237,8 +201,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--batch", type=int, default=4096, help="systems per GPU")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("IDAHIP_BENCH_LANES", "1")),
-                    help="slices of the rank's batch stepped concurrently on their own streams")
     ap.add_argument("--workload", choices=("linear_dense", "heat1d"), default="linear_dense",
                     help="linear_dense = config 3 (the headline, default N=512 B=4096); heat1d = config 4 (use --n 4096 --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,7 +254,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(prob, local_rank, lanes=args.lanes)
+    run = Runner(prob, local_rank)
     prob.pop("A", None)  # host copies no longer needed
     prob.pop("B", None)
 
@@ -347,8 +309,7 @@ def main():
                                     "config 4), N=%d, B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 with 10 outputs, every "
                                     "system restarts on its own at the end") % (args.n, args.batch),
                        "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
-                       "sharding": "independent systems, contiguous block per rank, no collective",
-                       "lanes_per_gpu": args.lanes},
+                       "sharding": "independent systems, contiguous block per rank, no collective"},
             "newton_iters_timed": iters_all,
             "roofline": roofline(dom, d, ab[dom], achieved, args.n if args.workload == "linear_dense" else -args.n),
             "kernel_classes_rank0": classes,
