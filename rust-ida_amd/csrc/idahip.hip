@@ -1,6 +1,7 @@
 // libidahip.so -- implementation of include/ida_hip.h (single translation unit; gfx950; -ffp-contract=off).
 #include "common.hpp"
 #include "lu_kernels.hpp"
+#include "lu_driver.hpp"
 #include "lu_rm.hpp"
 #include "problem_kernels.hpp"
 #include "solve_kernels.hpp"
@@ -87,6 +88,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     rc |= dalloc(c, &c->phi, (size_t)MXORDP1 * bn);
     rc |= dalloc(c, &c->lu, bnn); rc |= dalloc(c, &c->piv, bn); rc |= dalloc(c, &c->perm, bn);
     rc |= dalloc(c, &c->lu_info, (size_t)batch);
+    rc |= dalloc(c, &c->lu_redo, (size_t)batch);
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
@@ -115,6 +117,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     (void)hipMemsetAsync(c->delta, 0, bn * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->phi, 0, (size_t)MXORDP1 * bn * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->lu_info, 0, (size_t)batch * sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->lu_redo, 0, (size_t)batch * sizeof(int), c->stream);
     (void)hipStreamSynchronize(c->stream);
     *out = c;
     return 0;
@@ -125,7 +128,7 @@ int idahip_destroy(idahip_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -741,7 +744,7 @@ int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 3) return -1;
+    if (!c || variant < 0 || variant > 4) return -1;
     c->lu_variant = variant;
     return 0;
 }

@@ -79,7 +79,7 @@ def test_lorenz63_ensemble():
     check(problems.lorenz63(batch=96), touts=0.1 * np.arange(1, 21))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n,batch", [(12, 6), (33, 5), (64, 8), (100, 4), (192, 3)])
 def test_linear_dense_ensemble(n, batch, variant):
     from idahip import problems
@@ -106,7 +106,7 @@ def test_linear_dense_trace_of_one_system():
     assert np.array_equal(tr, rec[:, :3])  # every accepted step: same t_n, h_used, order -- bit for bit
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n,batch", [(40, 4), (130, 3)])
 def test_heat1d_ensemble(n, batch, variant):
     from idahip import problems
