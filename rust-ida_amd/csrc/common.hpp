@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ida_hip.h"
@@ -267,6 +268,22 @@ __device__ __forceinline__ int wave_min_i32f(int v) {
     v = dpp_imin<0x142, 0xa>(v);
     v = dpp_imin<0x143, 0xc>(v);
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// One update of the factorisation, a(i,j) -= a_kj * a_ik (dense.rs:151). FMA = false is the reference's arithmetic: the file
+// is compiled with -ffp-contract=off, so this is a multiply then a subtract. FMA = true is the contracted `fast` form.
+template <bool FMA>
+__device__ __forceinline__ double upd(double a, double u, double l) {
+    if (FMA) return __builtin_fma(-u, l, a);
+    return a - u * l;  // -ffp-contract=off: mul then sub (dense.rs:151)
 }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {

@@ -744,7 +744,7 @@ int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 4) return -1;
+    if (!c || variant < 0 || variant > 5) return -1;
     c->lu_variant = variant;
     return 0;
 }

@@ -38,6 +38,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
     const bool two_rows = c->lu_variant >= 3 || n > LU_MAX_N;
+    const bool fast = c->lu_variant == 5 && n <= LU_MAX_N;  // FMA-contracted updates (not bit-identical to the reference)
     if (c->lu_variant >= 2 || n > LU_MAX_N) {
         // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
         // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
@@ -58,8 +59,14 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 }
             } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
                 // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp)
-                hipLaunchKernelGGL((lu_wavepanel_kernel<false, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                hipLaunchKernelGGL((lu_wavepanel_kernel<false, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                // (two launches: the second one finishes the few systems whose matrices have exact zeros or special values)
+                if (fast) {
+                    hipLaunchKernelGGL((lu_wavepanel_kernel<true, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                    hipLaunchKernelGGL((lu_wavepanel_kernel<true, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                } else {
+                    hipLaunchKernelGGL((lu_wavepanel_kernel<false, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                    hipLaunchKernelGGL((lu_wavepanel_kernel<false, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                }
             } else {
             if (two_rows) panel2(k0, 0); else panel(k0, 0);
             if (n - k0 > NB) {
@@ -73,6 +80,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 const int ncb = (ntrail + 63) / 64;
                 if (n > LU_MAX_N)
                     hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                else if (fast)
+                    hipLaunchKernelGGL((lu_trail64w_kernel<LU_MAX_N, true>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 else
                     hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             }

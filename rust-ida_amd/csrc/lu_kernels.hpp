@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 //      stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU
 //      ops; two k-chunks of 32 through the strip buffer, the next strip's operands in flight behind the second chunk.
 //      49 KB of LDS per workgroup -> three workgroups per CU.
-template <int MAXROWS>
+template <int MAXROWS, bool FMA = false>
 __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
     constexpr int NB = 64, KC = 32;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1021,12 +1021,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             if (__ballot(z) == 0ull) {
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
-                    if (k > kk) u[k] -= ukk * Ls[kk][R0 + k];  // a(i,j) -= a_kj * a_ik, ascending kk
+                    if (k > kk) u[k] = upd<FMA>(u[k], ukk, Ls[kk][R0 + k]);  // a(i,j) -= a_kj * a_ik, ascending kk
             } else {
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
                     if (k > kk) {
-                        const double tn = u[k] - ukk * Ls[kk][R0 + k];
+                        const double tn = upd<FMA>(u[k], ukk, Ls[kk][R0 + k]);
                         u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
                     }
             }
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             for (int kk = 0; kk < KC; ++kk) {
                 const double ut = Us[kk][pl];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] -= ut * Ls[kk][KC + wave * 8 + i];
+                for (int i = 0; i < 8; ++i) v[i] = upd<FMA>(v[i], ut, Ls[kk][KC + wave * 8 + i]);
             }
         } else {
 #pragma unroll 4
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
                 const double ut = Us[kk][pl];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const double tn = v[i] - ut * Ls[kk][KC + wave * 8 + i];
+                    const double tn = upd<FMA>(v[i], ut, Ls[kk][KC + wave * 8 + i]);
                     v[i] = (ut != 0.0) ? tn : v[i];
                 }
             }
@@ -1096,18 +1096,43 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 
     auto chunk = [&](double (&c)[4][4], const int kbase) {
         if (!slow) {
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                double lv[4], uv[4];
+            // software-pipelined by hand: the operands of step k + 1 are requested from LDS before the arithmetic of step k
+            // is issued (the compiler places each step's four ds_read_b128 right in front of their first use, so a wave stalls
+            // for the LDS latency at every step; 16 more VGPRs buy that back)
+            double lvA[4], uvA[4], lvB[4], uvB[4];
+            auto rd = [&](const int k, double (&lv)[4], double (&uv)[4]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lv[i] = Lw[k][4 * a + i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) uv[j] = Us[kbase + k][4 * q + j];
+            };
+            auto mac = [&](const double (&lv)[4], const double (&uv)[4]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
+                    for (int i = 0; i < 4; ++i) c[i][j] = upd<FMA>(c[i][j], uv[j], lv[i]);  // dense.rs:151
+            };
+#ifndef IDAHIP_TRAIL_PIPE
+#define IDAHIP_TRAIL_PIPE 1
+#endif
+#if IDAHIP_TRAIL_PIPE
+            rd(0, lvA, uvA);
+#pragma unroll
+            for (int k = 0; k < KC; k += 2) {
+                rd(k + 1, lvB, uvB);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(lvA, uvA);
+                if (k + 2 < KC) rd(k + 2, lvA, uvA);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(lvB, uvB);
             }
+#else
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                rd(k, lvA, uvA);
+                mac(lvA, uvA);
+            }
+#endif
         } else {
 #pragma unroll 4
             for (int k = 0; k < KC; ++k) {
@@ -1120,7 +1145,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const double tn = c[i][j] - uv[j] * lv[i];
+                        const double tn = upd<FMA>(c[i][j], uv[j], lv[i]);
                         c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
                     }
             }

@@ -30,20 +30,6 @@
 
 namespace idahip {
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <bool FMA>
-__device__ __forceinline__ double upd(double a, double u, double l) {
-    if (FMA) return __builtin_fma(-u, l, a);
-    return a - u * l;  // -ffp-contract=off: mul then sub (dense.rs:151)
-}
-
 constexpr int WP_MAX_ROWS = 512;  // 8 slots of 64 lanes
 
 // A wave-uniform value as a per-lane value the optimiser cannot see through: `u == 0 ? a : b` then stays a pair of

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_HIP = os.path.join(_PKG, "csrc", "libidahip.so")
+LIB_HIP = os.environ.get("IDAHIP_LIB_HIP", os.path.join(_PKG, "csrc", "libidahip.so"))  # the override is for A/B builds (tools/)
 LIB_ENS = os.path.join(_PKG, "host", "libidaens.so")
 
 dp = C.POINTER(C.c_double)
