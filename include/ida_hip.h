@@ -140,11 +140,15 @@ int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCv
 int idahip_snapshot_initial(idahip_ctx* ctx);
 int idahip_restore_initial(idahip_ctx* ctx, const int32_t* hIdx, int nsys);
 
-/* LU implementation choice (all bit-identical to dense_get_rf): 3 = default: column-major work
- * matrix, 64-column super-panels built from two 32-column panels with two rows per lane, rank-64 trailing update in
- * wave-private 16-row strips; 2 = the same with one row per lane in the panel kernel; 0 = 32-column panels and rank-32
- * trailing update; 1 = row-major work matrix with 16-column sub-panels. 0-2 are kept for A/B measurements and as
- * cross-checks in the tests. Matrices with more than 1024 rows take the large-n pipeline whatever the variant. */
+/* LU implementation choice. All variants factor in 64-column super-panels with a rank-64 trailing
+ * update in wave-private 16-row strips and differ in how a super-panel is factored:
+ *   4 = default, bit-identical to dense_get_rf: one wavefront per matrix factors the whole super-panel (<= 512 live rows);
+ *   5 = `fast`: variant 4 with every update a(i,j) -= a_kj * a_ik contracted into one FMA (dense.rs:151 is a multiply then a
+ *       subtract): same pivots unless two candidates differ by less than the contraction error, factors equal to within
+ *       the usual backward error bound -- NOT bit-identical (tests/test_gpu_fastlu.py states and checks the tolerance);
+ *   3 = bit-identical: two 32-column panels with two rows per lane and a narrow update between them (also what the
+ *       leading super-panels of matrices with more than 512 rows use; more than 1024 rows: 8-column panels).
+ * Any other value is refused. */
 int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
 
 /* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the

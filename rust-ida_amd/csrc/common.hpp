@@ -57,13 +57,12 @@ struct idahip_ctx {
     int64_t* piv = nullptr;  // [batch][n]  reference pivots (dense.rs:118)
     int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
     // blocked-LU workspace
-    int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_uz = nullptr, *lu_redo = nullptr;
+    int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr;
     double* lu_l11 = nullptr;
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
-                         // 3: 64-column super-panels, two rows per lane in the panel kernel (lu_kernels.hpp)
-                         // 2: the same with one row per lane; 0: 32-column panels + rank-32 trailing kernel
-                         // 1: row-major work matrix, 16-column sub-panels, rank-64 trailing update (lu_rm.hpp)
+                         // 5: the same with FMA-contracted updates (`fast`, not bit-identical to the reference)
+                         // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // problem data
     double* params = nullptr;  // [batch][nparam]

@@ -2,7 +2,6 @@
 #include "common.hpp"
 #include "lu_kernels.hpp"
 #include "lu_driver.hpp"
-#include "lu_rm.hpp"
 #include "problem_kernels.hpp"
 #include "solve_kernels.hpp"
 #include "vector_kernels.hpp"
@@ -92,8 +91,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
-        rc |= dalloc(c, &c->lu_uz, (size_t)batch * (c->npad16 / 16 + 2));
-        rc |= dalloc(c, &c->lu_l11, (size_t)batch * (RM_SB + 1) * RM_SB);  // padded: the rolled TRSM reads past a row's end
+        rc |= dalloc(c, &c->lu_l11, (size_t)batch * L11_STRIDE);
     }
     if (kind == IDAHIP_LINEAR_DENSE) {
         rc |= dalloc(c, &c->A, bnn); rc |= dalloc(c, &c->B, bnn); rc |= dalloc(c, &c->C, bn);
@@ -128,7 +126,7 @@ int idahip_destroy(idahip_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_uz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -258,13 +256,6 @@ int idahip_ls_setup(idahip_ctx* c, double* dA, int64_t* dPiv, int32_t* hInfo, co
         KTimer kt(c, IDAHIP_K_LU, nsys);
         if (n <= TINY_N) {
             rc = lu_factor_batched(c, dA, nn, dA, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
-        } else if ((c->lu_variant == 1) && n <= LU_MAX_N) {
-            // transpose into the row-major ctx work matrix, factor there, write the factors back column-major into dA
-            RmWs w;
-            w.W = c->jw; w.wstride = nn; w.idx = d_idx; w.n = n;
-            const int nb64 = (n + 63) / 64;
-            hipLaunchKernelGGL(rm_transpose_in_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, w, (const double*)dA, nn);
-            rc = rm_factor_batched(c, c->jw, nn, dA, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
         } else {
             // factor in place in dA (physical row order), scatter rows into the ctx work matrix, copy back
             rc = lu_factor_batched(c, dA, nn, c->jw, nn, (long long*)dPiv, n, nullptr, d_idx, nsys);
@@ -375,7 +366,7 @@ int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out) {
 }
 
 // Jacobian kernels of IdaNLProblem::setup (jac at the current yy, yp, cj) into the LU work matrix
-int launch_jac(idahip_ctx* c, double* work, bool rm, const int* d_idx, const double* d_cj, int nsys) {
+int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj, int nsys) {
     const int n = c->n;
     const long nn = (long)n * n;
     switch (c->kind) {
@@ -388,25 +379,16 @@ int launch_jac(idahip_ctx* c, double* work, bool rm, const int* d_idx, const dou
                                (const double*)c->params, 3, d_idx, d_cj, nsys);
             break;
         case IDAHIP_LINEAR_DENSE: {
-            if (rm) {
-                const int nb64 = (n + 63) / 64;
-                hipLaunchKernelGGL(linear_jac_rm_kernel, dim3(nsys, nb64, nb64), dim3(256), 0, c->stream, work, (const double*)c->A,
-                                   (const double*)c->B, n, d_idx, d_cj);
-            } else {
-                int chunks = 1;
-                while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
-                hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A,
-                                   (const double*)c->B, nn, d_idx, d_cj, chunks);
-            }
+            int chunks = 1;
+            while ((long)nsys * chunks < 2048 && chunks < 64) chunks *= 2;
+            hipLaunchKernelGGL(linear_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, (const double*)c->A,
+                               (const double*)c->B, nn, d_idx, d_cj, chunks);
             break;
         }
         case IDAHIP_HEAT1D: {
             int chunks = 1;
             while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
-            if (rm)
-                hipLaunchKernelGGL(heat_jac_rm_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
-            else
-                hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+            hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
             break;
         }
     }
@@ -414,14 +396,13 @@ int launch_jac(idahip_ctx* c, double* work, bool rm, const int* d_idx, const dou
 }
 
 // batched getrf of the work matrices into ctx->lu / piv / perm, then the per-system info of the listed systems
-int factor_and_report(idahip_ctx* c, double* work, bool rm, const int* d_idx, const int32_t* hIdx, int nsys, int32_t* hInfo) {
+int factor_and_report(idahip_ctx* c, double* work, const int* d_idx, const int32_t* hIdx, int nsys, int32_t* hInfo) {
     const int n = c->n;
     const long nn = (long)n * n;
     int rc;
     {
         KTimer kt(c, IDAHIP_K_LU, nsys);
-        rc = rm ? rm_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys)
-                : lu_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys);
+        rc = lu_factor_batched(c, work, nn, c->lu, nn, (long long*)c->piv, n, c->perm, d_idx, nsys);
         if (rc) return rc;
         if ((rc = post_launch(c, "lu"))) return rc;
     }
@@ -475,12 +456,11 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
     const double* d_cj = ap.in(hCj, nsys);
     if ((rc = ap.upload())) return rc;
     double* work = (n <= TINY_N) ? c->lu : c->jw;
-    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);  // Jacobian written row-major for the factorisation
     {
         KTimer kt(c, IDAHIP_K_JAC, nsys);
-        if ((rc = launch_jac(c, work, rm, d_idx, d_cj, nsys))) return rc;
+        if ((rc = launch_jac(c, work, d_idx, d_cj, nsys))) return rc;
     }
-    return factor_and_report(c, work, rm, d_idx, hIdx, nsys, hInfo);
+    return factor_and_report(c, work, d_idx, hIdx, nsys, hInfo);
 }
 
 int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, int32_t* hInfo, const int32_t* hIdx,
@@ -499,18 +479,17 @@ int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, in
     if ((rc = ap.upload())) return rc;
     fill_sys_args(c, a, reset_ee);
     double* work = (n <= TINY_N) ? c->lu : c->jw;
-    const bool rm = n > TINY_N && n <= LU_MAX_N && (c->lu_variant == 1);
     // the linear dense residual sweeps A and B anyway: J = B + cj*A falls out of the same pass
-    const bool fused = c->kind == IDAHIP_LINEAR_DENSE && n > TINY_N && !rm;
+    const bool fused = c->kind == IDAHIP_LINEAR_DENSE && n > TINY_N;
     {
         KTimer kt(c, fused ? IDAHIP_K_SYS_JAC : IDAHIP_K_SYS, nsys);
         if ((rc = launch_sys(c, a, nsys, fused ? work : nullptr))) return rc;
     }
     if (!fused) {
         KTimer kt(c, IDAHIP_K_JAC, nsys);
-        if ((rc = launch_jac(c, work, rm, a.idx, a.cj, nsys))) return rc;
+        if ((rc = launch_jac(c, work, a.idx, a.cj, nsys))) return rc;
     }
-    return factor_and_report(c, work, rm, a.idx, hIdx, nsys, hInfo);
+    return factor_and_report(c, work, a.idx, hIdx, nsys, hInfo);
 }
 
 int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys) {
@@ -744,7 +723,7 @@ int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 5) return -1;
+    if (!c || variant < 3 || variant > 5) return -1;  // 3: panel + narrow update kernels, 4: wave-per-matrix panel (default), 5: 4 with FMA
     c->lu_variant = variant;
     return 0;
 }

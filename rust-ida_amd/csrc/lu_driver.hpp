@@ -7,7 +7,9 @@ namespace idahip {
 
 // ------------------------------------------------------------------------------------------------ host driver
 // Factor the matrices `work[b]` (column-major, physical row order, destroyed) of the listed systems into out[b]
-// (reference layout: rows at their pivoted positions). First-generation pipeline: panel(32) + fused trailing kernel.
+// (reference layout: rows at their pivoted positions). 64-column super-panels; per super-panel the panel factorisation
+// (by live rows: > 1024 lu_panelr, > 512 or variant 3 lu_panel2 + narrow update, else lu_wavepanel) and one launch of the
+// rank-64 trailing kernel; a final row scatter.
 inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* out, long ostride, long long* piv, long pstride,
                              int* perm, const int* d_idx, int nsys) {
     const int n = c->n;
@@ -22,85 +24,61 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo;
-    w.l11 = c->lu_l11; w.out = out; w.ostride = ostride;
+    w.l11 = c->lu_l11; w.out = out; w.ostride = ostride; w.l11ld = 64;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;
     constexpr int NB = LU_NB;
-    auto panel = [&](int k0, int lbase) {
-        const int threads = ((n - k0 + 63) / 64) * 64;
-        if (threads <= 512)
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
-        else
-            hipLaunchKernelGGL((lu_panel_kernel<NB, 1024, 4>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
-    };
-    auto panel2 = [&](int k0, int lbase) {  // two rows per lane: half the threads
+    auto panel2 = [&](int k0, int lbase) {  // two live rows per lane
         const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    const bool two_rows = c->lu_variant >= 3 || n > LU_MAX_N;
     const bool fast = c->lu_variant == 5 && n <= LU_MAX_N;  // FMA-contracted updates (not bit-identical to the reference)
-    if (c->lu_variant >= 2 || n > LU_MAX_N) {
-        // 64-column super-panels: half as many sweeps over the trailing matrix. Each super-panel is two 32-column
-        // panels; the first one's update reaches the second through a narrow (32-column) launch of the trailing
-        // kernel, the rest of the matrix sees both at once in the rank-64 kernel.
-        w.l11ld = 64;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            if (n - k0 > LU_MAX_N) {
-                // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
-                // update of the rest of the super-panel; the rank-64 trailing kernel below is the same
-                constexpr int NBS = 8;
-                const int cend = (k0 + 64 < n) ? k0 + 64 : n;
-                const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
-                for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
-                    hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
-                    if (k0 + lb + NBS < cend)
-                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
-                                           cend, lb * 65);
-                }
-            } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
-                // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp)
-                // (two launches: the second one finishes the few systems whose matrices have exact zeros or special values)
-                if (fast) {
-                    hipLaunchKernelGGL((lu_wavepanel_kernel<true, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                    hipLaunchKernelGGL((lu_wavepanel_kernel<true, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                } else {
-                    hipLaunchKernelGGL((lu_wavepanel_kernel<false, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                    hipLaunchKernelGGL((lu_wavepanel_kernel<false, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                }
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        if (n - k0 > LU_MAX_N) {
+            // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
+            // update of the rest of the super-panel
+            constexpr int NBS = 8;
+            const int cend = (k0 + 64 < n) ? k0 + 64 : n;
+            const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
+            for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
+                hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
+                if (k0 + lb + NBS < cend)
+                    hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                                       cend, lb * 65);
+            }
+        } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
+            // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp); the second launch finishes
+            // the few systems whose matrices have exact zeros or special values (it returns at once for the others)
+            if (fast) {
+                hipLaunchKernelGGL((lu_wavepanel_kernel<true, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                hipLaunchKernelGGL((lu_wavepanel_kernel<true, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
             } else {
-            if (two_rows) panel2(k0, 0); else panel(k0, 0);
+                hipLaunchKernelGGL((lu_wavepanel_kernel<false, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                hipLaunchKernelGGL((lu_wavepanel_kernel<false, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+            }
+        } else {
+            // two 32-column panels; the first one's update reaches the second through a narrow (32-column) launch of the
+            // trailing kernel
+            panel2(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
                 hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 2>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0);
-                if (two_rows) panel2(k0 + NB, NB); else panel(k0 + NB, NB);
-            }
-            }
-            const int ntrail = n - k0 - 64;
-            if (ntrail > 0) {
-                const int ncb = (ntrail + 63) / 64;
-                if (n > LU_MAX_N)
-                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-                else if (fast)
-                    hipLaunchKernelGGL((lu_trail64w_kernel<LU_MAX_N, true>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-                else
-                    hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                panel2(k0 + NB, NB);
             }
         }
-        hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB, n > LU_MAX_N ? 8 : 0,
-                           c->lu_variant >= 4 ? WP_MAX_ROWS : 0);
-        return 0;
-    }
-    w.l11ld = NB;
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        panel(k0, 0);
-        const int ntrail = n - k0 - NB;
+        const int ntrail = n - k0 - 64;
         if (ntrail > 0) {
             const int ncb = (ntrail + 63) / 64;
-            hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 4>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, n, 0);
+            if (n > LU_MAX_N)
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+            else if (fast)
+                hipLaunchKernelGGL((lu_trail64w_kernel<LU_MAX_N, true>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+            else
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
         }
     }
-    const int cpb = 32;
-    hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + cpb - 1) / cpb), dim3(256), 0, c->stream, w, out, ostride, perm, cpb, NB, 0, 0);
+    hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB, n > LU_MAX_N ? 8 : 0,
+                       c->lu_variant >= 4 ? WP_MAX_ROWS : 0);
     return 0;
 }
 

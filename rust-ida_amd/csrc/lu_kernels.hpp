@@ -13,15 +13,14 @@
 //     resolve exactly as the reference's scan does. Column-major storage makes physical row swaps a strided,
 //     uncoalesced disaster on a GPU; here every access is a coalesced column segment.
 //   * right-looking blocked algorithm over the whole list of matrices (lock-step batch, thousands of workgroups per
-//     launch). Default pipeline (LU variant 3), per 64-column super-panel:
-//       lu_panel2 (k0)      : one workgroup per matrix, two live rows per lane, 32 panel entries per row in registers;
-//                             fused-DPP + LDS arg-max, pivot row broadcast through LDS;
-//       lu_trail<32> narrow : the first panel's update of the super-panel's other 32 columns;
-//       lu_panel2 (k0 + 32) : second half of the super-panel;
-//       lu_trail64          : per (matrix, 64 trailing columns): pivot-row gather, U12 = L11^-1 A12 in LDS, then
-//                             A22 -= L21 U12 on 64x64 tiles, rank 64, 4x4 register tile per thread, operands from LDS.
-//     Variants 0 and 2 (one row per lane: lu_panel; 32-column panels with a rank-32 lu_trail) are the earlier pipelines,
-//     kept for A/B measurements and as cross-checks in the tests.
+//     launch), 64-column super-panels. Default pipeline (LU variant 4), per super-panel:
+//       lu_wavepanel (lu_wavepanel.hpp): one wavefront per matrix factors the whole super-panel (<= 512 live rows);
+//       lu_trail64w              : per (matrix, 64 trailing columns): pivot-row gather, U12 = L11^-1 A12 in LDS, then
+//                                  A22 -= L21 U12 in wave-private 16-row strips, rank 64, 4x4 register tile per lane.
+//     Variant 3 (cross-check in the tests, and the path for more than 512 live rows) factors the super-panel with
+//       lu_panel2 (k0) -> lu_trail<32> narrow (the first panel's update of the other 32 columns) -> lu_panel2 (k0 + 32):
+//       one workgroup per matrix, two live rows per lane, 32 panel entries per row in registers, fused-DPP + LDS arg-max.
+//     More than 1024 live rows: eight 8-column panels with eight rows per lane (lu_panelr) per super-panel.
 //   * a final pass scatters rows to their pivoted positions (the reference layout the solve kernels stream).
 // Blocking changes neither the per-element operation order nor any operand, only when each update is applied.
 #pragma once
@@ -57,199 +56,9 @@ __global__ void lu_init_kernel(LuWs w) {
     if (threadIdx.x == 0) w.info[b] = 0;
 }
 
-// ------------------------------------------------------------------------------------------------ panel
-// One workgroup per matrix, one live row per thread, the row's NB panel entries in registers.
-//  * The column loop is a real (rolled) loop: registers rotate by one column per step -- the update of column j is
-//    written into register j-1, a(j-1) <- a(j) - prow(j)*a_ik, at no extra instruction -- so the pivot column is always
-//    register 0 and a step is ~250 instructions (a fully unrolled NB x NB triangle is > 100 KB of code run once).
-//  * ONE LDS-only barrier per column: every wave reduces its own arg-max on the DPP crossbar and its winning lane
-//    publishes (|a|, position, the whole candidate row, 1/pivot, zero mask) speculatively; after the barrier every
-//    thread picks the global winner among the <= 16 wave candidates and reads that wave's row. No serial owner
-//    section, and the barrier does not drain the multiplier stores (raw s_barrier + lgkmcnt only).
+// LDS-only workgroup barrier: unlike __syncthreads() it does not drain the vector-memory counter, so global stores issued
+// inside a latency-critical loop stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int NB, int MAXT, int WPE>
-__global__ __launch_bounds__(MAXT, WPE) void lu_panel_kernel(LuWs w, int k0, int lbase) {
-    constexpr int NW = MAXT / 64;
-    constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
-    static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
-    const int b = w.idx[blockIdx.x];
-    if (w.info[b] != 0) return;
-    const int n = w.n;
-    double* __restrict__ A = w.mats + (long)b * w.mstride;
-    int* __restrict__ pos = w.pos + (long)b * n;
-    int* __restrict__ live = w.live + (long)b * n;
-    int* __restrict__ prow = w.prow + (long)b * n;
-    long long* __restrict__ piv = w.piv + (long)b * w.pstride;
-    double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
-
-    const int m = n - k0;
-    const int wd = m < NB ? m : NB;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-
-    __shared__ __align__(16) double s_row[2][NW][LDR];
-    __shared__ unsigned s_kh[2][16], s_kl[2][16];
-    __shared__ __align__(16) int s_p[2][16];
-    __shared__ unsigned long long s_zm[2][NW];
-    __shared__ int s_r[2][NW];
-    __shared__ int s_cnt[NW];
-
-    if (t < 32) {  // slots of waves that do not exist in this launch never win
-        (&s_kh[0][0])[t] = 0u;
-        (&s_kl[0][0])[t] = 0u;
-        (&s_p[0][0])[t] = 0x7fffffff;
-    }
-    const bool valid = t < m;
-    const int r = valid ? live[t] : 0;
-    int mypos = valid ? pos[r] : 0x7fffffff;
-    double a[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] = (valid && j < wd) ? A[(long)(k0 + j) * n + r] : 0.0;
-    __syncthreads();
-
-    bool alive = valid;
-    int ownk = -1;
-    bool failed = false;
-
-    // one elimination step; returns false on a zero pivot. The column loop below runs two steps per trip so that the
-    // rotating row registers ping-pong between two sets instead of being copied back at every loop back-edge.
-    auto step = [&](const int k) -> bool {
-        const int kc = k0 + k;
-        const int par = k & 1;
-        // candidate key of a live row: the bit pattern of |a| (monotone for non-negative doubles) with the always-clear
-        // sign bit set, so that 0 means "no candidate here"; ties go to the lowest position. NaN only wins if it sits
-        // at position kc (dense.rs:111-117 scan semantics).
-        unsigned kh = 0u, kl = 0u;
-        if (alive) {
-            const double v = fabs(a[0]);
-            kh = (unsigned)__double2hiint(v) | 0x80000000u;
-            kl = (unsigned)__double2loint(v);
-            if (v != v) {
-                kh = (mypos == kc) ? 0xfff00000u : 0u;  // +inf, or never
-                kl = 0u;
-            }
-        }
-        // every lane forms the reciprocal of its own candidate pivot: the divide overlaps the reduction below instead
-        // of sitting, single-lane, on the critical path of the winner.   mult = a(k,k).recip()  (dense.rs:134)
-        const double myrecip = 1.0 / a[0];
-        const unsigned mh = wave_max_u32<false>(kh);
-        const unsigned ml = wave_max_u32<false>(kh == mh ? kl : 0u);
-        const bool top = kh != 0u && kh == mh && kl == ml;
-        const int pm = wave_min_i32f<false>(top ? mypos : 0x7fffffff);
-        const bool cand = top && mypos == pm;  // this wave's candidate row (one lane, or none)
-        if (cand) {
-#pragma unroll
-            for (int j = 0; j < NB; j += 2) {
-                double2 q;
-                q.x = a[j];
-                q.y = a[j + 1];
-                *reinterpret_cast<double2*>(&s_row[par][wave][j]) = q;
-            }
-            s_row[par][wave][NB] = myrecip;
-            s_r[par][wave] = r;
-        }
-        // zero mask of the candidate row (dense.rs:148): lanes 1..NB-1 re-read one entry each, one ballot
-        {
-            const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
-            const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
-            if (lane == 0) {
-                s_zm[par][wave] = zm;
-                s_kh[par][wave] = mh;  // 0 when the wave has no live row
-                s_kl[par][wave] = ml;
-                s_p[par][wave] = pm;
-            }
-        }
-        lds_barrier();
-        // global winner among <= 16 wave candidates: lane q < 16 takes candidate q, 4-step DPP fold inside the row
-        int bp, bw;
-        {
-            const int q = lane & 15;
-            const unsigned ch = s_kh[par][q], cl = s_kl[par][q];
-            const int cp = s_p[par][q];
-            const unsigned bh = wave_max_u32<true>(ch);
-            const unsigned bl = wave_max_u32<true>(ch == bh ? cl : 0u);
-            // lowest position among the candidates attaining the maximum; the wave index rides in the low 4 bits of the
-            // key (positions are < 2^27, so (pos << 4 | q) fits in 31 bits)
-            const int kmin = wave_min_i32f<true>((ch == bh && cl == bl) ? ((cp << 4) | q) : 0x7fffffff);
-            bp = kmin >> 4;
-            bw = kmin & 15;
-        }
-        const double pk = s_row[par][bw][0];
-        if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
-            if (t == 0) w.info[b] = kc + 1;
-            return false;
-        }
-        if (t == 0) piv[kc] = (long long)bp;
-        const bool owner = alive && (mypos == bp);
-        if (owner) {
-            prow[kc] = r;
-            ownk = k;
-            alive = false;
-            mypos = kc;
-        }
-        // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
-        if (wave == 0 && lane < NB && k + lane < wd)
-            A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
-        // the arithmetic below runs on every lane (rows that are not live compute values nobody reads): no divergent
-        // region around the rotating registers, so the compiler updates them in place instead of copying all of them
-        const bool upd = !owner && alive;
-        if (upd && mypos == kc) mypos = bp;  // the row that sat at position k moves to the pivot's old position
-        const double aik = a[0] * s_row[par][bw][NB];
-        if (upd) A[(long)kc * n + r] = aik;  // the multiplier is final (coalesced column store)
-        const unsigned long long zmv = s_zm[par][bw];
-        const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
-        if (zm == 0ull) {
-#pragma unroll
-            for (int jc = 0; jc < NB; jc += 8) {
-                double u[8];
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
-                    u[j] = q.x;
-                    u[j + 1] = q.y;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (jc + j >= 1) a[jc + j - 1] = a[jc + j] - u[j] * aik;  // dense.rs:151, rotated one column
-            }
-        } else {
-#pragma unroll
-            for (int j = 1; j < NB; ++j) a[j - 1] = ((zm >> j) & 1ull) ? a[j] : a[j] - s_row[par][bw][j] * aik;
-        }
-        a[NB - 1] = 0.0;
-        return true;
-    };
-#pragma unroll 1
-    for (int k = 0; k < wd; ++k)
-        if (!step(k)) { failed = true; break; }
-    if (failed) return;
-
-    // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
-    if (valid) pos[r] = mypos;
-    __syncthreads();  // the multipliers stored above are visible to the whole workgroup
-    // lbase = columns of the enclosing super-panel already factored by an earlier panel launch (0, or NB for the second
-    // half of a 2*NB super-panel): this pivot row's multipliers against those columns belong to the same L11
-    if (ownk >= 0) {
-        const int kq = lbase + ownk;
-        const double* __restrict__ src = A + (long)(k0 - lbase) * n + r;
-        for (int j0 = 0; j0 < kq; j0 += 8) {  // eight independent loads in flight, not one L2 round trip per multiplier
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (j0 + u < kq) ? src[(long)(j0 + u) * n] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j0 + u < kq) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
-        }
-    }
-    const unsigned long long bal = __ballot(alive);
-    if (lane == 0) s_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int base = 0;
-    for (int q = 0; q < wave; ++q) base += s_cnt[q];
-    if (alive) live[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
-}
 
 // ------------------------------------------------------------------------------------------------ panel, two rows per thread
 // Same contract as lu_panel_kernel. A step of the panel is one long dependent chain (arg-max -> LDS -> barrier ->

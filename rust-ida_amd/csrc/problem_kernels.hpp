@@ -223,30 +223,6 @@ __global__ __launch_bounds__(256) void linear_jac_kernel(double* __restrict__ ma
     }
 }
 
-// Same Jacobian written ROW-major (the layout the factorisation works in): W[r*n + c] = B(r,c) + cj*A(r,c).
-// A, B are column-major, so a 64x64 tile goes through LDS: coalesced reads along r, coalesced writes along c.
-__global__ __launch_bounds__(256) void linear_jac_rm_kernel(double* __restrict__ mats, const double* __restrict__ A, const double* __restrict__ Bm,
-                                                            int n, const int* __restrict__ idx, const double* __restrict__ cjs) {
-    const int b = idx[blockIdx.x];
-    const double cj = cjs[blockIdx.x];
-    const long nn = (long)n * n;
-    const double* __restrict__ Ab = A + (long)b * nn;
-    const double* __restrict__ Bb = Bm + (long)b * nn;
-    double* __restrict__ W = mats + (long)b * nn;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
-    __shared__ double tile[64][65];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int cc = grp; cc < 64; cc += 4) {
-        if (c0 + cc < n && r0 + lane < n) {
-            const long e = (long)(c0 + cc) * n + r0 + lane;
-            tile[cc][lane] = Bb[e] + cj * Ab[e];
-        }
-    }
-    __syncthreads();
-    for (int rr = grp; rr < 64; rr += 4)
-        if (r0 + rr < n && c0 + lane < n) W[(long)(r0 + rr) * n + c0 + lane] = tile[lane][rr];
-}
-
 // ------------------------------------------------------------------------------------------------ heat 1-D
 __global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* __restrict__ params) {
     extern __shared__ __align__(16) double sm[];
@@ -275,30 +251,6 @@ __global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* 
         else r = a.yp[vb + i] - coef * ((syy[i - 1] - 2.0 * syy[i]) + syy[i + 1]);
         a.delta[vb + i] = r;
         a.savres[vb + i] = r;
-    }
-}
-
-// row-major variant: W[i*n + j] = J(i, j)
-__global__ __launch_bounds__(256) void heat_jac_rm_kernel(double* __restrict__ mats, int n, const double* __restrict__ params,
-                                                          const int* __restrict__ idx, const double* __restrict__ cjs, int chunks) {
-    const int b = idx[blockIdx.x];
-    const double cj = cjs[blockIdx.x];
-    const double coef = params[b];
-    double* __restrict__ J = mats + (long)b * n * n;
-    const int per = (n + chunks - 1) / chunks;  // rows per block
-    const int ibeg = blockIdx.y * per;
-    const int iend = (ibeg + per < n) ? ibeg + per : n;
-    for (int i = ibeg; i < iend; ++i) {
-        for (int j = threadIdx.x; j < n; j += 256) {
-            double v = 0.0;
-            if (i == 0 || i == n - 1) {
-                v = (j == i) ? 1.0 : 0.0;
-            } else {
-                if (j == i) v = cj + 2.0 * coef;
-                else if (j == i - 1 || j == i + 1) v = -coef;
-            }
-            J[(long)i * n + j] = v;
-        }
     }
 }
 

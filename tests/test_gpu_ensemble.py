@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 CNT = ("nst", "nre", "nje", "nsetups", "nni", "netf", "ncfn", "n_attempts")
 
 
-def run_gpu(prob, touts=None, lu_variant=0):
+def run_gpu(prob, touts=None, lu_variant=4):
     import idahip
     from idahip import problems
     ctx = problems.make_ctx(prob)
@@ -41,7 +41,7 @@ def run_oracle(prob, touts=None, nthreads=8):
                           params=prob.get("params"), A=prob.get("A"), B=prob.get("B"), c=prob.get("c"), nthreads=nthreads)
 
 
-def check(prob, touts=None, lu_variant=0):
+def check(prob, touts=None, lu_variant=4):
     ens, yy, yp = run_gpu(prob, touts, lu_variant)
     ref = run_oracle(prob, touts)
     assert (ref["status"] == 0).all()
@@ -79,7 +79,7 @@ def test_lorenz63_ensemble():
     check(problems.lorenz63(batch=96), touts=0.1 * np.arange(1, 21))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [3, 4])
 @pytest.mark.parametrize("n,batch", [(12, 6), (33, 5), (64, 8), (100, 4), (192, 3)])
 def test_linear_dense_ensemble(n, batch, variant):
     from idahip import problems
@@ -106,7 +106,7 @@ def test_linear_dense_trace_of_one_system():
     assert np.array_equal(tr, rec[:, :3])  # every accepted step: same t_n, h_used, order -- bit for bit
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [3, 4])
 @pytest.mark.parametrize("n,batch", [(40, 4), (130, 3)])
 def test_heat1d_ensemble(n, batch, variant):
     from idahip import problems

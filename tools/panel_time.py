@@ -11,7 +11,7 @@ from idahip import problems
 n, B = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 p = problems.linear_dense(n=n, batch=B, procs=int(os.environ.get("IDAHIP_GEN_PROCS", "16")))
 ctx = problems.make_ctx(p)
-ctx.set_lu_variant(int(os.environ.get("LU_VARIANT", "3")))
+ctx.set_lu_variant(int(os.environ.get("LU_VARIANT", "4")))
 ctx.upload(idahip.F_YY, p["yy0"]); ctx.upload(idahip.F_YP, p["yp0"])
 ctx.timing(True)
 for r in range(3):
