@@ -100,6 +100,22 @@ inline int fail(idahip_ctx* c, int code, const char* fmt, ...) {
         if (e__ != hipSuccess) return idahip::fail((c), -100, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
+// Every entry point of the C ABI runs on the ctx's own device whatever device is current in the calling thread (one host
+// thread may drive several GPUs); the caller's current device is put back on return.
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    explicit DevGuard(const idahip_ctx* c) : DevGuard(c ? c->device : -1) {}
+    ~DevGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
 // One call's host->device arguments and device->host results, carved from a ring slot.
 struct ArgPack {
     idahip_ctx* c;
@@ -107,6 +123,7 @@ struct ArgPack {
     size_t in_bytes = 0;   // bytes to upload (prefix of the slot)
     size_t off = 0;
     size_t out_begin = 0, out_end = 0;
+    bool overflow = false;
 
     int begin(idahip_ctx* ctx) {
         c = ctx;
@@ -121,9 +138,15 @@ struct ArgPack {
     }
     static size_t align(size_t x) { return (x + 63) & ~(size_t)63; }
     // copy `bytes` from host into the slot; returns the device address
+    // (a request that does not fit the slot is not staged: `overflow` makes upload() / fetch() fail before anything of this
+    // call is launched or read back -- the largest call today, predict, stages about 110 bytes per system of slot_cap's 256)
     template <class T>
     const T* in(const T* src, size_t count) {
         off = align(off);
+        if (off + count * sizeof(T) > c->slot_cap) {
+            overflow = true;
+            return (const T*)s->d;
+        }
         memcpy(s->h + off, src, count * sizeof(T));
         const T* d = (const T*)(s->d + off);
         off += count * sizeof(T);
@@ -131,6 +154,7 @@ struct ArgPack {
         return d;
     }
     int upload() {
+        if (overflow) return fail(c, -5, "argument staging slot too small (%zu bytes)", c->slot_cap);
         if (in_bytes) IDAHIP_HIP(c, hipMemcpyAsync(s->d, s->h, in_bytes, hipMemcpyHostToDevice, c->stream));
         return 0;
     }
@@ -138,6 +162,10 @@ struct ArgPack {
     template <class T>
     T* out(size_t count) {
         off = align(off);
+        if (off + count * sizeof(T) > c->slot_cap) {
+            overflow = true;
+            return nullptr;  // checked by the callers through ok() before the launch
+        }
         if (out_begin == 0 && out_end == 0) out_begin = off;
         T* d = (T*)(s->d + off);
         off += count * sizeof(T);
@@ -146,8 +174,10 @@ struct ArgPack {
     }
     template <class T>
     const T* host_of(const T* dptr) const { return (const T*)(s->h + ((const char*)dptr - s->d)); }
+    int ok() { return overflow ? fail(c, -5, "argument staging slot too small (%zu bytes)", c->slot_cap) : 0; }
     // download the output region and wait for it
     int fetch() {
+        if (overflow) return ok();
         if (out_end > out_begin)
             IDAHIP_HIP(c, hipMemcpyAsync(s->h + out_begin, s->d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, c->stream));
         IDAHIP_HIP(c, hipStreamSynchronize(c->stream));

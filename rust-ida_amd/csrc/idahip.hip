@@ -72,8 +72,10 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
     c->npad16 = (n + 15) & ~15;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) { delete c; return -100; }
+    int ndev = 0;
+    if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
+    DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
+    if (hipSetDevice(device) != hipSuccess) { delete c; return -100; }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -98,7 +100,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     }
     if (kind == IDAHIP_LORENZ63) { c->nparam = 3; rc |= dalloc(c, &c->params, (size_t)batch * 3); }
     if (kind == IDAHIP_HEAT1D) { c->nparam = 1; rc |= dalloc(c, &c->params, (size_t)batch); }
-    c->slot_cap = (size_t)batch * 192 + 4096;
+    c->slot_cap = (size_t)batch * 256 + 4096;  // per call: <= ~110 B of scalars per system (predict) + list ids + results
     for (int i = 0; i < NSLOT && !rc; ++i) {
         if (hipHostMalloc((void**)&c->slots[i].h, c->slot_cap) != hipSuccess) rc = -100;
         else if (hipMalloc((void**)&c->slots[i].d, c->slot_cap) != hipSuccess) rc = -100;
@@ -122,8 +124,8 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
 }
 
 int idahip_destroy(idahip_ctx* c) {
+    DevGuard dev_guard__(c);
     if (!c) return 0;
-    (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
@@ -147,12 +149,14 @@ int idahip_n(const idahip_ctx* c) { return c ? c->n : -1; }
 int idahip_batch(const idahip_ctx* c) { return c ? c->batch : -1; }
 
 int idahip_sync(idahip_ctx* c) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int idahip_set_tolerances(idahip_ctx* c, double rtol, const double* hAtol, int natol) {
+    DevGuard dev_guard__(c);
     if (!c || !hAtol) return -1;
     if (natol != 1 && natol != c->n) return fail(c, -2, "natol must be 1 or n");
     c->rtol = rtol;
@@ -168,6 +172,7 @@ int idahip_set_tolerances(idahip_ctx* c, double rtol, const double* hAtol, int n
 }
 
 int idahip_set_problem_params(idahip_ctx* c, int first, int count, const double* hParams, int nparam) {
+    DevGuard dev_guard__(c);
     if (!c || !hParams) return -1;
     if (!c->params || nparam != c->nparam) return fail(c, -2, "problem kind takes %d parameters per system", c->nparam);
     if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
@@ -176,6 +181,7 @@ int idahip_set_problem_params(idahip_ctx* c, int first, int count, const double*
 }
 
 int idahip_set_linear_dense(idahip_ctx* c, int first, int count, const double* hA, const double* hB, const double* hC) {
+    DevGuard dev_guard__(c);
     if (!c || !hA || !hB || !hC) return -1;
     if (c->kind != IDAHIP_LINEAR_DENSE) return fail(c, -2, "not a LINEAR_DENSE ctx");
     if (first < 0 || count < 0 || first + count > c->batch) return fail(c, -2, "system range out of bounds");
@@ -187,6 +193,7 @@ int idahip_set_linear_dense(idahip_ctx* c, int first, int count, const double* h
 }
 
 int idahip_upload(idahip_ctx* c, idahip_field f, int first, int count, const double* h) {
+    DevGuard dev_guard__(c);
     if (!c || !h) return -1;
     double* d = field_ptr(c, f);
     if (!d) return fail(c, -2, "unknown field %d", (int)f);
@@ -197,6 +204,7 @@ int idahip_upload(idahip_ctx* c, idahip_field f, int first, int count, const dou
 }
 
 int idahip_download(idahip_ctx* c, idahip_field f, int first, int count, double* h) {
+    DevGuard dev_guard__(c);
     if (!c || !h) return -1;
     double* d = field_ptr(c, f);
     if (!d) return fail(c, -2, "unknown field %d", (int)f);
@@ -207,6 +215,7 @@ int idahip_download(idahip_ctx* c, idahip_field f, int first, int count, double*
 }
 
 int idahip_download_lu(idahip_ctx* c, int sys, double* hLU, int64_t* hPiv) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     if (sys < 0 || sys >= c->batch) return fail(c, -2, "system out of range");
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
@@ -217,23 +226,27 @@ int idahip_download_lu(idahip_ctx* c, int sys, double* hLU, int64_t* hPiv) {
 }
 
 void* idahip_dev_alloc(idahip_ctx* c, size_t bytes) {
+    DevGuard dev_guard__(c);
     void* p = nullptr;
     if (!c || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     return p;
 }
 int idahip_dev_free(idahip_ctx* c, void* d) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
     IDAHIP_HIP(c, hipFree(d));
     return 0;
 }
 int idahip_memcpy_h2d(idahip_ctx* c, void* d, const void* h, size_t bytes) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
     IDAHIP_HIP(c, hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 int idahip_memcpy_d2h(idahip_ctx* c, void* h, const void* d, size_t bytes) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
     IDAHIP_HIP(c, hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
@@ -242,6 +255,7 @@ int idahip_memcpy_d2h(idahip_ctx* c, void* h, const void* d, size_t bytes) {
 
 // ------------------------------------------------------------------------------------------------ LSolver
 int idahip_ls_setup(idahip_ctx* c, double* dA, int64_t* dPiv, int32_t* hInfo, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!dA || !dPiv || !hInfo) return fail(c, -2, "null argument");
@@ -280,6 +294,7 @@ int idahip_ls_setup(idahip_ctx* c, double* dA, int64_t* dPiv, int32_t* hInfo, co
 
 int idahip_ls_solve(idahip_ctx* c, const double* dLU, const int64_t* dPiv, double* dX, const double* dB, double /*tol*/,
                     const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!dLU || !dPiv || !dX || !dB) return fail(c, -2, "null argument");
@@ -309,6 +324,7 @@ int idahip_ls_solve(idahip_ctx* c, const double* dLU, const int64_t* dPiv, doubl
 }
 
 int idahip_wrms(idahip_ctx* c, const double* dX, const double* dW, double* hOut, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!dX || !dW || !hOut) return fail(c, -2, "null argument");
@@ -318,6 +334,7 @@ int idahip_wrms(idahip_ctx* c, const double* dX, const double* dW, double* hOut,
     if ((rc = ap.begin(c))) return rc;
     const int* d_idx = ap.in(hIdx, nsys);
     double* d_out = ap.out<double>(nsys);
+    if ((rc = ap.ok())) return rc;
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, nsys);
@@ -425,6 +442,7 @@ void fill_sys_args(idahip_ctx* c, SysArgs& a, int reset_ee) {
 }  // namespace
 
 int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hTn || !hCj) return fail(c, -2, "null argument");
@@ -445,6 +463,7 @@ int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int rese
 }
 
 int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
@@ -465,6 +484,7 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
 
 int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, int reset_ee, int32_t* hInfo, const int32_t* hIdx,
                          int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hTn || !hCj || !hInfo) return fail(c, -2, "null argument");
@@ -493,6 +513,7 @@ int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, in
 }
 
 int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hScale || !hDelnrm) return fail(c, -2, "null argument");
@@ -503,6 +524,7 @@ int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, con
     const int* d_idx = ap.in(hIdx, nsys);
     const double* d_scale = ap.in(hScale, nsys);
     double* d_out = ap.out<double>(nsys);
+    if ((rc = ap.ok())) return rc;
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_NEWTON_ITER, nsys);
@@ -526,6 +548,7 @@ int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, con
 
 // ------------------------------------------------------------------------------------------------ stepper vector ops
 int idahip_init_first(idahip_ctx* c, double* hYpnorm, double* hPhi0Nrm, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hYpnorm || !hPhi0Nrm) return fail(c, -2, "null argument");
@@ -534,6 +557,7 @@ int idahip_init_first(idahip_ctx* c, double* hYpnorm, double* hPhi0Nrm, const in
     if ((rc = ap.begin(c))) return rc;
     const int* d_idx = ap.in(hIdx, nsys);
     double* d_out = ap.out<double>(2 * (size_t)nsys);
+    if ((rc = ap.ok())) return rc;
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, nsys);
@@ -550,6 +574,7 @@ int idahip_init_first(idahip_ctx* c, double* hYpnorm, double* hPhi0Nrm, const in
 }
 
 int idahip_scale_phi1(idahip_ctx* c, const double* hFac, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hFac) return fail(c, -2, "null argument");
@@ -568,6 +593,7 @@ int idahip_scale_phi1(idahip_ctx* c, const double* hFac, const int32_t* hIdx, in
 }
 
 int idahip_predict(idahip_ctx* c, const int32_t* hKkNs, const double* hBeta, const double* hGamma, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hKkNs || !hBeta || !hGamma) return fail(c, -2, "null argument");
@@ -590,6 +616,7 @@ int idahip_predict(idahip_ctx* c, const int32_t* hKkNs, const double* hBeta, con
 }
 
 int idahip_post_newton(idahip_ctx* c, const double* hCj, const int32_t* hKk, double* hNorms, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hCj || !hKk || !hNorms) return fail(c, -2, "null argument");
@@ -602,6 +629,7 @@ int idahip_post_newton(idahip_ctx* c, const double* hCj, const int32_t* hKk, dou
     const double* d_cj = ap.in(hCj, nsys);
     const int* d_kk = ap.in(hKk, nsys);
     double* d_out = ap.out<double>(4 * (size_t)nsys);
+    if ((rc = ap.ok())) return rc;
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, nsys);
@@ -615,6 +643,7 @@ int idahip_post_newton(idahip_ctx* c, const double* hCj, const int32_t* hKk, dou
 }
 
 int idahip_restore(idahip_ctx* c, const int32_t* hKkNs, const double* hCvals, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hKkNs || !hCvals) return fail(c, -2, "null argument");
@@ -637,6 +666,7 @@ int idahip_restore(idahip_ctx* c, const int32_t* hKkNs, const double* hCvals, co
 
 int idahip_complete_step(idahip_ctx* c, const int32_t* hKused, const double* hCk, int maxord, double* hPhi0Nrm, int32_t* hEwtBad,
                          const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hKused || !hCk || !hPhi0Nrm || !hEwtBad) return fail(c, -2, "null argument");
@@ -651,6 +681,7 @@ int idahip_complete_step(idahip_ctx* c, const int32_t* hKused, const double* hCk
     const double* d_ck = ap.in(hCk, nsys);
     double* d_out = ap.out<double>(nsys);
     int* d_bad = ap.out<int>(nsys);
+    if ((rc = ap.ok())) return rc;
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, nsys);
@@ -669,6 +700,7 @@ int idahip_complete_step(idahip_ctx* c, const int32_t* hKused, const double* hCk
 }
 
 int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCvals, const double* hDvals, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!hKord || !hCvals || !hDvals) return fail(c, -2, "null argument");
@@ -691,6 +723,7 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
 }
 
 int idahip_snapshot_initial(idahip_ctx* c) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     const size_t bn = (size_t)c->batch * c->n;
     int rc = 0;
@@ -705,6 +738,7 @@ int idahip_snapshot_initial(idahip_ctx* c) {
 }
 
 int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
     if (rc) return rc;
     if (!c->ic_y) return fail(c, -2, "idahip_restore_initial before idahip_snapshot_initial");
@@ -723,6 +757,7 @@ int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
+    DevGuard dev_guard__(c);
     if (!c || variant < 3 || variant > 5) return -1;  // 3: panel + narrow update kernels, 4: wave-per-matrix panel (default), 5: 4 with FMA
     c->lu_variant = variant;
     return 0;
@@ -730,11 +765,13 @@ int idahip_set_lu_variant(idahip_ctx* c, int variant) {
 
 // ------------------------------------------------------------------------------------------------ measurement
 int idahip_timing_enable(idahip_ctx* c, int on) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     c->timing = on != 0;
     return 0;
 }
 int idahip_timing_get(idahip_ctx* c, idahip_kclass k, double* ms, int64_t* launches, int64_t* systems) {
+    DevGuard dev_guard__(c);
     if (!c || k < 0 || k >= IDAHIP_K_COUNT) return -1;
     if (ms) *ms = c->k_ms[k];
     if (launches) *launches = c->k_launches[k];
@@ -742,6 +779,7 @@ int idahip_timing_get(idahip_ctx* c, idahip_kclass k, double* ms, int64_t* launc
     return 0;
 }
 int idahip_timing_reset(idahip_ctx* c) {
+    DevGuard dev_guard__(c);
     if (!c) return -1;
     for (int k = 0; k < IDAHIP_K_COUNT; ++k) {
         c->k_ms[k] = 0.0;

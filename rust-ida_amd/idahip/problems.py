@@ -56,17 +56,16 @@ def _linear_system(n, b):
 _SHARED = {}
 
 
-def _shared_array(shape):
-    """float64 array in anonymous shared memory (inherited by forked workers, freed with the last reference)."""
-    import mmap
-    nbytes = int(np.prod(shape)) * 8
-    mm = mmap.mmap(-1, max(nbytes, 8))
-    return np.frombuffer(mm, dtype=np.float64, count=int(np.prod(shape))).reshape(shape)
-
-
 def _fill_range(args):
-    n, first, lo, hi, limit_blas = args
-    A, Bm, c, y0, yp0 = _SHARED["arrays"]
+    """Worker: fill systems [lo, hi) of the five output arrays (process-local arrays, or shared memory blocks by name)."""
+    n, first, lo, hi, limit_blas, shm_names, shapes = args
+    handles = []
+    if shm_names is None:
+        A, Bm, c, y0, yp0 = _SHARED["arrays"]
+    else:
+        from multiprocessing import shared_memory
+        handles = [shared_memory.SharedMemory(name=nm) for nm in shm_names]
+        A, Bm, c, y0, yp0 = [np.ndarray(sh, dtype=np.float64, buffer=h.buf) for sh, h in zip(shapes, handles)]
 
     def fill():
         for s in range(lo, hi):
@@ -81,29 +80,71 @@ def _fill_range(args):
             fill()
     else:
         fill()
+    del A, Bm, c, y0, yp0
+    for h in handles:
+        h.close()
     return hi - lo
 
 
-def linear_dense(n=512, batch=4096, first=0, procs=1, threads=None):
+_KEEP = []  # shared memory blocks behind arrays handed out by linear_dense(procs > 1): alive as long as the process
+
+
+def linear_dense(n=512, batch=4096, first=0, procs=1, nthreads=1):
     """Config 3/5 -- synthetic random linear dense index-1 DAE F = A y' + B y - c, systems [first, first+batch).
-    Matrices are returned column-major per system (array[s, j, i] = M_s(i, j)). `procs` > 1 generates with forked
-    worker processes into shared memory (call before the process touches the GPU)."""
-    if threads is not None:  # backwards-compatible alias
-        procs = threads
+    Matrices are returned column-major per system (array[s, j, i] = M_s(i, j)).
+    `procs` > 1 generates with worker processes of a fork server into named shared memory: safe also after this process
+    has initialised the GPU (nothing is forked from it). `nthreads` > 1 generates with a thread pool instead (numpy's
+    generators and LAPACK calls release the GIL only in part: about 1.5x on 8 cores)."""
     shapes = [(batch, n, n), (batch, n, n), (batch, n), (batch, n), (batch, n)]
+    if nthreads > 1 and procs <= 1 and batch >= 2 * nthreads:
+        from concurrent.futures import ThreadPoolExecutor
+        arrays = [np.empty(sh) for sh in shapes]
+        A, Bm, c, y0, yp0 = arrays
+
+        def fill(lo, hi):
+            for s in range(lo, hi):
+                A[s], Bm[s], c[s], y0[s], yp0[s] = _linear_system(n, first + s)
+            return hi - lo
+
+        step = max(1, batch // (nthreads * 8))
+        try:
+            from threadpoolctl import threadpool_limits
+            limiter = threadpool_limits(limits=1)  # one BLAS thread per pool thread
+        except ImportError:
+            limiter = None
+        try:
+            with ThreadPoolExecutor(nthreads) as pool:
+                done = sum(pool.map(lambda lo: fill(lo, min(batch, lo + step)), range(0, batch, step)))
+        finally:
+            if limiter is not None:
+                limiter.restore_original_limits()
+        assert done == batch
+        return {"kind": "linear_dense", "n": n, "A": A, "B": Bm, "c": c, "yy0": y0, "yp0": yp0, "rtol": 1.0e-6,
+                "atol": np.array([1.0e-8]), "touts": 0.1 * np.arange(1, 11)}
     if procs > 1 and batch >= 2 * procs:
+        # worker processes forked from a clean fork server (itself started by exec, so none of them inherits this
+        # process's threads, locks or -- if the GPU is already in use here -- ROCm runtime); results come back through
+        # named shared memory, unlinked as soon as the workers are done
         import multiprocessing as mp
-        arrays = [_shared_array(sh) for sh in shapes]
-        _SHARED["arrays"] = arrays
-        step = max(1, batch // (procs * 4))
-        jobs = [(n, first, lo, min(batch, lo + step), True) for lo in range(0, batch, step)]
-        with mp.get_context("fork").Pool(procs) as pool:
-            assert sum(pool.map(_fill_range, jobs)) == batch
-        _SHARED.pop("arrays")
+        from multiprocessing import shared_memory
+        blocks = [shared_memory.SharedMemory(create=True, size=max(8, int(np.prod(sh)) * 8)) for sh in shapes]
+        try:
+            step = max(1, batch // (procs * 4))
+            names = [b.name for b in blocks]
+            jobs = [(n, first, lo, min(batch, lo + step), True, names, shapes) for lo in range(0, batch, step)]
+            ctx = mp.get_context("forkserver")
+            ctx.set_forkserver_preload(["numpy"])
+            with ctx.Pool(procs) as pool:
+                assert sum(pool.map(_fill_range, jobs)) == batch
+        finally:
+            for b in blocks:
+                b.unlink()
+        arrays = [np.ndarray(sh, dtype=np.float64, buffer=b.buf) for sh, b in zip(shapes, blocks)]
+        _KEEP.extend(blocks)
     else:
         arrays = [np.empty(sh) for sh in shapes]
         _SHARED["arrays"] = arrays
-        _fill_range((n, first, 0, batch, False))
+        _fill_range((n, first, 0, batch, False, None, shapes))
         _SHARED.pop("arrays")
     A, Bm, c, y0, yp0 = arrays
     return {"kind": "linear_dense", "n": n, "A": A, "B": Bm, "c": c, "yy0": y0, "yp0": yp0, "rtol": 1.0e-6,

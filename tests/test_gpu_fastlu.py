@@ -1,0 +1,90 @@
+"""The `fast` LU (idahip_set_lu_variant(5): every update a(i,j) -= a_kj * a_ik contracted into one FMA, dense.rs:151 being a
+multiply then a subtract) against the exact one (variant 4, bit-identical to dense_get_rf).
+
+Stated tolerance. An FMA rounds once where the reference rounds twice, so the fast factors are those of Gaussian
+elimination with partial pivoting in a slightly different -- not less accurate -- arithmetic. What is promised, and checked
+here on every system: the componentwise backward error of the fast factors obeys the same bound as the exact ones,
+    |P J - L U| <= 4 n u |L| |U|   (u = 2^-53; Higham, Accuracy and Stability, thm 9.3 gives gamma_n = n u / (1 - n u)),
+pivots may differ only where two candidates agree to rounding, and the ensemble integration (config 3) takes the same
+numbers of steps, error-test failures, Newton iterations and linear setups up to a reported number of systems."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def colmajor(mats):
+    return np.ascontiguousarray(np.transpose(mats, (0, 2, 1)))
+
+
+def gpu_lu(mats, variant):
+    import idahip
+    B, n, _ = mats.shape
+    ctx = idahip.Ctx("linear_dense", n, B)
+    ctx.set_lu_variant(variant)
+    dA = ctx.dev_array(colmajor(mats))
+    dP = ctx.dev_empty(8 * B * n)
+    rc, info = ctx.ls_setup(dA, dP, None)
+    assert rc == 0 and not info.any()
+    return np.transpose(ctx.to_host(dA, (B, n, n)), (0, 2, 1)), ctx.to_host(dP, (B, n), dtype=np.int64)
+
+
+def backward_error_ratio(J, lu, piv):
+    """max_ij |P J - L U| / (n u |L| |U|)."""
+    n = J.shape[0]
+    L = np.tril(lu, -1) + np.eye(n)
+    U = np.triu(lu)
+    PJ = J.copy()
+    for k in range(n):  # the reference's row interchanges, dense.rs:125-131
+        l = int(piv[k])
+        if l != k:
+            PJ[[k, l]] = PJ[[l, k]]
+    bound = n * 2.0 ** -53 * (np.abs(L) @ np.abs(U))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(bound > 0, np.abs(PJ - L @ U) / bound, 0.0)
+    return float(r.max())
+
+
+@pytest.mark.parametrize("n", [64, 200, 512])
+def test_fast_factors_obey_the_backward_error_bound(n):
+    rng = np.random.default_rng(n)
+    B = 6
+    mats = rng.standard_normal((B, n, n))
+    lu4, piv4 = gpu_lu(mats, 4)
+    lu5, piv5 = gpu_lu(mats, 5)
+    for s in range(B):
+        info_o, lu_o, piv_o = O.getrf(mats[s])
+        assert np.array_equal(lu4[s], lu_o) and np.array_equal(piv4[s], piv_o)      # the exact variant is the reference
+        r4, r5 = backward_error_ratio(mats[s], lu4[s], piv4[s]), backward_error_ratio(mats[s], lu5[s], piv5[s])
+        assert r4 <= 4.0 and r5 <= 4.0, (n, s, r4, r5)                               # the stated tolerance
+        if np.array_equal(piv4[s], piv5[s]):                                           # same pivots: factors agree to rounding
+            scale = np.abs(lu4[s]).max()
+            assert np.abs(lu5[s] - lu4[s]).max() <= 1e-9 * scale * n
+    assert not np.array_equal(lu4, lu5)  # it is a different arithmetic: bit-identity would mean the FMA path did not run
+
+
+def test_fast_lu_keeps_the_step_and_iteration_counts_of_config3():
+    """Config 3's generator (N = 512; 256 systems here, all 4096 in bench.py's `fast_vs_exact` report): integrate with the
+    exact and with the fast LU and compare nst / netf / ncfn / nni / nsetups / kused per system. The factors only enter
+    through Newton corrections, which are iterated to convergence, so the counts are expected to be equal; the number of
+    systems where they are not is reported, and asserted small."""
+    import idahip
+    from idahip import problems
+    p = problems.linear_dense(n=512, batch=256, procs=8)
+    res = {}
+    for variant in (4, 5):
+        ctx = problems.make_ctx(p)
+        ctx.set_lu_variant(variant)
+        ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+        status, tret, reached = ens.solve_schedule(p["touts"])
+        assert (status == 0).all()
+        c = ens.counters()
+        res[variant] = (np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), ens.yy())
+        ens.close()
+    differ = int((res[4][0] != res[5][0]).any(axis=0).sum())
+    rel = np.abs(res[5][1] - res[4][1]).max() / np.abs(res[4][1]).max()
+    print("fast vs exact LU on 256 systems of config 3: %d systems with different counts, max rel. state difference %.2e" % (differ, rel))
+    assert differ <= 8          # a count changes only where a convergence or error test sits within rounding of its threshold
+    assert rel <= 1e-6          # rtol of the integration: both are solutions to tolerance

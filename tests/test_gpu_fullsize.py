@@ -3,7 +3,7 @@
 The oracle cannot integrate 4096 systems of N = 512 in test time, so the full-size run is checked through properties that
 do not depend on the batch size, plus the oracle itself on a sample:
   * a sample of systems spread over the batch is bit-identical (state, step sizes, orders, every counter) to the
-    oracle integrating those systems alone;
+    oracle integrating those systems alone, over the whole horizon t = 0 .. 1 (all ten outputs of config 3);
   * batch-position independence: the same systems integrated as a small batch of their own give the same bits as
     inside the full batch (no cross-talk between workgroups, index lists, staging rings);
   * the batched LU of all 4096 Jacobians satisfies P J = L U to rounding on sampled systems and its forward/back
@@ -27,12 +27,12 @@ CNT = ("nst", "nre", "nje", "nsetups", "nni", "netf", "ncfn", "n_attempts")
 def full():
     import idahip
     from idahip import problems
-    # forked numpy workers (fork, no exec; the children never touch the GPU and leave through os._exit)
+    # numpy worker processes of a fork server (nothing is forked from this process, whose ROCm runtime is live by now)
     procs = max(1, min(32, (os.cpu_count() or 1) // 2))
     prob = problems.linear_dense(n=N, batch=B, procs=procs)
     ctx = problems.make_ctx(prob)
     ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
-    touts = [float(t) for t in prob["touts"][:3]]  # three Ida::solve calls: t = 0.1, 0.2, 0.3
+    touts = [float(t) for t in prob["touts"]]  # the ten Ida::solve calls of config 3: t = 0.1 .. 1.0
     for tout in touts:
         status, tret = ens.solve(tout)
         assert (status == 0).all()
@@ -105,6 +105,61 @@ def test_full_batch_lu_factors_and_solves(full):
         b = rng.standard_normal(N)
         x = O.getrs(lu, piv, b)
         assert np.abs(J @ x - b).max() <= 1e-11 * N * (np.abs(J) @ np.abs(x)).max()  # backward-stable solve
+
+
+@pytest.mark.parametrize("shard", [3, 7])
+def test_config5_shard_inputs_match_the_oracle(shard):
+    """Config 5 = config 3's generator over 32,768 systems, shard s = systems [4096 s, 4096 (s + 1)). Its inputs differ
+    from config 3's only through the per-system seed, so a sample of a late shard (first, middle, last systems of shards
+    3 and 7), integrated over the whole horizon on the HIP path, must equal the oracle bit for bit like shard 0 does."""
+    import idahip
+    from idahip import problems
+    first = 4096 * shard
+    offs = np.array([0, 1, 2047, 2048, 4094, 4095])
+    parts = [problems.linear_dense(n=N, batch=1, first=first + int(o)) for o in offs]
+    p = dict(parts[0])
+    for k in ("A", "B", "c", "yy0", "yp0"):
+        p[k] = np.concatenate([q[k] for q in parts])
+    touts = [float(t) for t in p["touts"]]
+    ctx = problems.make_ctx(p)
+    ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+    status, tret, reached, yo, ypo = ens.solve_schedule(touts, outputs=True)
+    assert (status == 0).all() and (reached == len(touts)).all()
+    ref = O.run_ensemble("linear_dense", N, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, A=p["A"], B=p["B"], c=p["c"],
+                         nthreads=len(offs))
+    assert (ref["status"] == 0).all()
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(yo, ref["yy"]) and np.array_equal(ypo, ref["yp"])
+    assert np.array_equal(ens.real("hused"), ref["hused"])
+    ens.close()
+
+
+def test_stream_driver_at_full_n(full):
+    """idaens_stream (the driver bench.py times) at N = 512: systems restart from their initial conditions when they reach
+    t = 1; whatever pass a system is in, its accepted steps are those of the oracle's fresh integration."""
+    import idahip
+    from idahip import problems
+    ids = np.array([5, 1500, 4000, 4095])
+    sub = sub_problem(full["prob"], ids)
+    ens = idahip.Ensemble(problems.make_ctx(sub), sub["yy0"], sub["yp0"])
+    steps = []
+    for s in range(len(ids)):
+        o = O.OracleIda("linear_dense", N, sub["yy0"][s], sub["yp0"][s], sub["rtol"], sub["atol"], A=sub["A"][s], B=sub["B"][s],
+                        c=sub["c"][s])
+        O.lib().oracle_ida_record_steps(o.h, 1)
+        for t in sub["touts"]:
+            assert o.solve(float(t))[0] == 0
+        steps.append(o.recorded_steps())
+    passes = 0
+    while passes < 2 * len(ids):
+        passes = ens.stream(sub["touts"], 5, stagger_rounds=3)
+        nst, tn, hu, ku = ens.counter("nst"), ens.real("tn"), ens.real("hused"), ens.counter("kused")
+        for s in range(len(ids)):
+            if nst[s] > 0:
+                assert np.array_equal(steps[s][nst[s] - 1, :3], [tn[s], hu[s], float(ku[s])]), (s, nst[s])
+    ens.close()
 
 
 def test_config2_lorenz63_full_batch():

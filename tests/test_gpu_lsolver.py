@@ -223,3 +223,27 @@ def test_empty_and_invalid_system_lists():
     assert np.array_equal(ctx.to_host(dA, (B, n, n)), before)
     with pytest.raises(idahip.IdaHipError):
         idahip.Ctx("linear_dense", 5000, 1).ls_setup(ctx.dev_empty(8), ctx.dev_empty(8), [0])  # n > 4096: refused
+
+
+def test_entry_points_run_on_the_ctx_device_whatever_device_is_current():
+    """A ctx belongs to the device it was created on: every entry point switches to it and puts the caller's current
+    device back (one host thread driving several GPUs). Needs two visible GPUs to see a switch; on a
+    one-GPU box it still checks that the calls leave the current device alone."""
+    import torch
+    import idahip
+    ndev = torch.cuda.device_count()
+    other = 1 if ndev > 1 else 0
+    n, B = 48, 3
+    rng = np.random.default_rng(12)
+    mats = rng.standard_normal((B, n, n))
+    info_o, lu_o, piv_o = oracle_lu(mats)
+    ctx = idahip.Ctx("linear_dense", n, B, device=0)
+    torch.cuda.set_device(other)
+    dA = ctx.dev_array(colmajor(mats))     # allocation, copies, launches: all with device `other` current in this thread
+    dP = ctx.dev_empty(8 * B * n)
+    rc, info = ctx.ls_setup(dA, dP, None)
+    assert torch.cuda.current_device() == other
+    lu = np.transpose(ctx.to_host(dA, (B, n, n)), (0, 2, 1))
+    assert rc == 0 and np.array_equal(lu, lu_o) and np.array_equal(ctx.to_host(dP, (B, n), dtype=np.int64), piv_o)
+    assert torch.cuda.current_device() == other
+    torch.cuda.set_device(0)
