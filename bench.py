@@ -1,29 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- Newton iterations / second (fp64) of the batched BDF/Newton hot path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run, one
-rank per GPU. Prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0). For N > 1 it is normally launched
+by torch.distributed.run, one rank per GPU; started by hand without a launcher (`python bench.py --gpus 2`, no WORLD_SIZE in
+the environment) it starts the N ranks itself as child processes, before anything of torch or HIP is loaded.
 
 Workload (BASELINE.json configs[2]): synthetic random linear dense index-1 DAE
 F = A y' + B y - c, N = 512, batch B = 4096 systems per GPU (distinct matrices per system, all device resident),
 rtol 1e-6, atol 1e-8, integrated from t = 0 to t = 1 with outputs every 0.1 (ten Ida::solve calls per system, handed over
-as one schedule: systems do not wait for each other at the outputs). Throughput mode: a system that has reached t = 1 is
-created anew from its initial conditions and integrates again, so the batch never drains and the measured rate is that of
-an endless stream of such integrations -- it does not depend on which rounds K and W select (the systems' first starts are
-staggered over 96 rounds and 200 untimed rounds precede the warm-up, so the batch is spread evenly over the phases of an
-integration).
-A "step" is one lock-step step attempt of the whole batch: set_coeffs -> predict -> Newton solve (residual, Jacobian +
-batched LU when the reference's rule asks for it, 1..4 triangular solves + WRMS norms) -> error test -> complete_step
-or restore, for every one of the B systems. Nothing is skipped: every accepted step is bit-identical to the CPU
-oracle's (tests/test_gpu_ensemble.py, incl. test_streaming_restarts_reproduce_fresh_integrations).
-value = (Newton iterations of all systems on all ranks during the K timed steps) / (max over ranks of the wall time
-of those steps), inputs already resident in HBM.
+as one schedule: systems do not wait for each other at the outputs). Other workloads (parity configs, not the headline):
+`--workload lorenz63 --n 3 --batch 1024` (config 2), `--workload heat1d --n 4096 --batch 256` (config 4).
+
+What is timed.
+  value        Throughput mode (idaens_stream): a system that has reached t = 1 is created anew from its initial conditions
+               and integrates again, so the batch never drains; a "step" is one lock-step step attempt of the whole batch
+               (set_coeffs -> predict -> Newton solve with residual, Jacobian + batched LU when the reference's rule asks
+               for it, 1..4 triangular solves + WRMS norms -> error test -> complete_step or restore, for every one of the B
+               systems). value = Newton iterations of all systems on all ranks during the K timed steps / max over ranks of
+               the wall time of those steps, inputs resident in HBM, NO event timers or extra synchronisation inside.
+  whole_pass   SURVEY 8(d)'s protocol next to it (N = 1 only): the whole ensemble from fresh state, t = 0 -> 1, median of 3
+               passes (Newton iterations of the pass / its wall time).
+  kernel_classes_rank0, roofline, lu_plus_solve
+               measured in further, untimed repetitions of the K steps with HIP-event timers on the ctx stream: once per
+               kernel class, once per kernel of the LU (the dominant kernel's `roofline`).
+  fast_vs_exact  (N = 1 only) one more whole pass with the FMA-contracted LU (idahip_set_lu_variant(5)): its rate, its
+               LU + solve figure, and the number of systems whose nst / netf / ncfn / nni / nsetups / kused differ from the
+               exact pass. `value` is always measured with the exact LU.
 Multi-GPU (config 5): the ensemble shards embarrassingly -- rank r integrates systems [4096 r, 4096 (r+1)); no data-path
 collective; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the time.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,7 +43,10 @@ for p in (os.path.join(ROOT, "rust-ida_amd"), os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+VALU_FMA_TFLOPS = 78.6       # fp64 vector peak with FMA = 1/2 x 157.3 TFLOP/s fp32 vector (same guide), 2.4 GHz
+VALU_UNFUSED_TFLOPS = 39.3   # a multiply and a subtract per update (the reference's arithmetic, dense.rs:151): half of it
+PMC_SUMMARY = os.path.join("profiles", "r02_bench_summary.json")  # committed rocprofv3 --pmc passes of this command
 
 
 def algorithmic_bytes(n, workload="linear_dense"):
@@ -42,6 +54,8 @@ def algorithmic_bytes(n, workload="linear_dense"):
     if workload == "heat1d":  # three-point residual, dense Jacobian written (mostly zeros)
         return {"newton_iter": 8 * n * n + 40 * n + 8, "sys": 56 * n, "jac": 8 * n * n, "sys_jac": 8 * n * n + 56 * n,
                 "lu": 16 * n * n + 8 * n}
+    if workload == "lorenz63":
+        return {"newton_iter": 8 * n * n + 40 * n + 8, "sys": 56 * n + 24, "jac": 8 * n * n + 8 * n + 24, "sys_jac": 0, "lu": 16 * n * n + 8 * n}
     return {
         "newton_iter": 8 * n * n + 40 * n + 8,   # getrs 8N^2+24N, + neg/scale/axpy/wrms vectors 16N+8
         "sys": 16 * n * n + 40 * n,              # residual of the linear dense DAE
@@ -51,99 +65,86 @@ def algorithmic_bytes(n, workload="linear_dense"):
     }
 
 
-KERNEL_OF_CLASS = {
-    "lu": "batched getrf = the lu_panel2 / lu_trail / lu_trail64 / lu_finalize kernel launches of one idahip_nls_lsetup call",
-    "sys": "linear_sys_kernel<2, false>", "newton_iter": "newton_iter_kernel", "jac": "linear_jac_kernel",
-    "sys_jac": "linear_sys_kernel<2, true>",
-}
+def getrf_flops(n):
+    return 2.0 * n ** 3 / 3.0 - n ** 2 / 2.0 - n / 6.0
 
 
-def profiled_traffic(cls):
-    """HBM bytes per system of the kernel class from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes, gfx950-corrected; profiles/README.md). PMC counters cannot be read inside this process, so the
-    figure is the profiled one for the same command, or None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_w0_summary.json")
+def trailing_work(n):
+    """Algorithmic work of lu_trail64w_kernel per matrix (all its launches of one factorisation): for every 64-column
+    super-panel with mrem rows and ntrail columns right of it, U12 = L11^-1 A12 (64 x 63 / 2 updates per column) and
+    A22 -= L21 U12 (mrem x ntrail x 64 updates); an update = 2 flops. Bytes: A22 read + written once per super-panel, L21 and
+    the pivot rows read, U12 written."""
+    flops, nbytes, launches = 0.0, 0.0, 0
+    for k0 in range(0, n, 64):
+        m = n - k0 - 64
+        if m <= 0:
+            break
+        launches += 1
+        flops += 2.0 * (m * m * 64 + m * (64 * 63 // 2))
+        nbytes += 16.0 * m * m + 8.0 * 64 * (m + 2 * m)
+    return flops, nbytes, launches
+
+
+def profiled_traffic(kernel_prefix):
+    """HBM bytes per matrix of one LU kernel from the committed rocprofv3 PMC summary of this command (separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/README.md). Counters cannot be read inside this process, so
+    this is the profiled figure of the same command at the commit named in the summary, or None when it is absent."""
     try:
-        s = json.load(open(path))
+        s = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
     except Exception:
         return None
-    names = {"lu": ("lu_",), "sys": ("linear_sys_kernel<2, false>", "linear_sys_kernel<1, false>"),
-             "sys_jac": ("linear_sys_kernel<2, true>", "linear_sys_kernel<1, true>"),
-             "newton_iter": ("newton_iter_kernel",), "jac": ("linear_jac_kernel",)}[cls]
-    tot = 0.0
-    for k, v in s["kernels"].items():
-        if k.startswith(names) and "hbm_read_GB_total" in v:
+    tot, systems = 0.0, 0
+    for k, v in s.get("kernels", {}).items():
+        if k.startswith(kernel_prefix) and "hbm_read_GB_total" in v:
             tot += v["hbm_read_GB_total"] + v["hbm_write_GB_total"]
-    systems = s["bench"]["kernel_classes_rank0"].get(cls, {}).get("systems", 0)
-    return {"hbm_bytes_per_system": int(tot * 1e9 / max(1, systems)), "source": "profiles/r01_bench_w0_summary.json"} if tot else None
-
-
-def lu_plus_solve(tim, n):
-    """The kernel-level figure north_star states its target on: one batched getrf + one getrs per system, algorithmic
-    bytes (24 N^2 + 32 N) over the device time per system of the lu class plus the newton_iter class
-    (whose kernel is the getrs with the Newton vector updates fused in)."""
-    lu, ni = tim["lu"], tim["newton_iter"]
-    if lu["systems"] == 0 or ni["systems"] == 0:
+    systems = s.get("bench", {}).get("lu_kernels_rank0", {}).get("lu_trail", {}).get("matrices", 0) or \
+        s.get("bench", {}).get("kernel_classes_rank0", {}).get("lu", {}).get("systems", 0)
+    if not tot or not systems:
         return None
-    us = 1e3 * (lu["ms"] / lu["systems"] + ni["ms"] / ni["systems"])
-    gbs = (24 * n * n + 32 * n) / (us * 1e-6) / 1e9
-    return {"us_per_system": round(us, 3), "GB/s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-            "note": "reference-exact arithmetic (unfused mul, sub) caps the getrf at 23 % of the HBM roofline (DESIGN.md section 4)"}
+    return {"hbm_bytes_per_matrix": int(tot * 1e9 / systems), "source": PMC_SUMMARY, "commit": s.get("commit")}
 
 
-def roofline(dom, d, alg_bytes, achieved, n):
-    """The `roofline` object of the JSON line for the kernel class with the most device time. achieved = algorithmic bytes
-    per launch / average launch duration (HIP events on the ctx stream, timed region); traffic = measured HBM bytes per
-    launch, i.e. the committed PMC figure per system x the systems one launch of this run processed."""
-    spl = d["systems"] / max(1, d["launches"])
-    tr = profiled_traffic(dom) if n == 512 else None  # the committed PMC passes are of the N = 512 headline workload
-    extra = {}
-    if n < 0:  # not the headline workload: no committed traffic profile
-        n = -n
-        tr = None
-    if dom == "lu" and d["ms"] > 0:
-        # the reference-exact elimination is an unfused mul + sub per update: 2 fp64 VALU ops, ~n^3/3 updates per matrix;
-        # ceiling = 256 CUs x 64 lanes x 2.4 GHz / 2 ops
-        upd = (n ** 3 / 3.0) * d["systems"] / (d["ms"] * 1e-3)
-        peak = 256 * 64 * 2.4e9 / 2.0
-        extra = {"valu": {"achieved": round(upd / 1e12, 3), "peak": round(peak / 1e12, 2), "unit": "T updates/s (mul + sub, fp64)",
-                          "frac": round(upd / peak, 4)}}
-    return {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], **extra, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None if tr is None else int(tr["hbm_bytes_per_system"] * spl),
-            "traffic_bytes_per_system": None if tr is None else tr["hbm_bytes_per_system"],
-            "traffic_source": None if tr is None else tr["source"],
-            "algorithmic_bytes_per_launch": int(alg_bytes * spl), "algorithmic_bytes_per_system": alg_bytes,
-            "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "systems_per_launch": round(spl, 1),
-            "note": "a launch of the lu class is one batched getrf (all its kernel launches); for the LU the fp64 VALU ceiling "
-                    "binds before HBM (DESIGN.md section 4)"}
+def lu_plus_solve(tim, n, arithmetic):
+    """The kernel-level figure north_star states its target on: one batched getrf + one getrs per system, algorithmic bytes
+    (24 N^2 + 32 N) over the device time per system of the lu class plus the newton_iter class (whose kernel
+    is the getrs with the Newton vector updates fused in)."""
+    lu, ni = tim["lu"], tim["newton_iter"]
+    if lu["systems"] == 0 or ni["systems"] == 0 or lu["ms"] <= 0:
+        return None
+    us_lu, us_ni = 1e3 * lu["ms"] / lu["systems"], 1e3 * ni["ms"] / ni["systems"]
+    gbs = (24 * n * n + 32 * n) / ((us_lu + us_ni) * 1e-6) / 1e9
+    tf = getrf_flops(n) / (us_lu * 1e-6) / 1e12
+    peak = VALU_FMA_TFLOPS if arithmetic == "fma" else VALU_UNFUSED_TFLOPS
+    return {"arithmetic": arithmetic, "getrf_us_per_matrix": round(us_lu, 3), "getrs_us_per_system": round(us_ni, 3),
+            "GB/s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "getrf_TFLOP/s": round(tf, 2), "getrf_frac_of_valu_peak": round(tf / peak, 4), "valu_peak_TFLOP/s": peak}
 
 
-# IDAHIP_BENCH_TIME_ALL=1 (tools/profile_bench.sh): the HIP-event kernel-class timers run from the first launch of the process
-# (spin-up and warm-up included), so that kernel_classes_rank0 can be checked against a rocprofv3 kernel trace of the same
-# process; `value` is unaffected.
+# IDAHIP_BENCH_TIME_ALL=1 (tools/profile_bench.sh): the per-kernel HIP-event timers of the LU run from the first launch of
+# the process (spin-up, warm-up, every repetition), so that `lu_kernels_rank0` can be checked against a rocprofv3 kernel
+# trace of the same process. `value` then carries the timers' synchronisations and is marked as such.
 TIME_ALL = os.environ.get("IDAHIP_BENCH_TIME_ALL") == "1"
 
 
-class Lane:
-    """One contiguous slice of the rank's systems in throughput mode (idaens_stream): the ten Ida::solve calls of the
-    workload are one output schedule per system, a system that has reached t = 1 is created anew (Ida::new from its
-    initial conditions) and starts over at once. The batch never drains: every lock-step round works on every system,
-    each somewhere else in its integration, so the rate does not depend on which rounds are timed."""
+class Runner:
+    """The rank's whole batch as one ensemble on one device context and stream, in throughput mode (idaens_stream): the ten
+    Ida::solve calls of the workload are one output schedule per system, a system that has reached the end is created anew
+    (Ida::new from its initial conditions) and starts over at once. The batch never drains: every lock-step round works on
+    every system, each somewhere else in its integration."""
 
     STAGGER = 96   # the systems' first starts are spread over this many rounds (about one integration)
     SPIN_UP = 200  # untimed rounds before the warm-up: the stagger plus one more integration
 
-    def __init__(self, prob, device, stream=None):
+    def __init__(self, prob, device):
         import idahip
         from idahip import problems
         self.prob = prob
-        self.ctx = problems.make_ctx(prob, device=device, stream=stream)
+        self.ctx = problems.make_ctx(prob, device=device)
         self.ens = idahip.Ensemble(self.ctx, prob["yy0"], prob["yp0"])
         if TIME_ALL:
-            self.ctx.timing(True)
+            self.ctx.timing(2)
             self.ctx.timing_reset()
-        self.passes = self.ens.stream(prob["touts"], self.SPIN_UP, stagger_rounds=self.STAGGER)
+        self.ens.stream(prob["touts"], self.SPIN_UP, stagger_rounds=self.STAGGER)
 
     def total_iters(self):
         return self.ens.total_newton_iters()
@@ -151,38 +152,51 @@ class Lane:
     def step(self):
         """Exactly one lock-step round."""
         before = self.ens.total_rounds()
-        self.passes = self.ens.stream(self.prob["touts"], 1)
+        self.ens.stream(self.prob["touts"], 1)
         assert self.ens.total_rounds() == before + 1
 
-
-class Runner:
-    """The rank's whole batch as one ensemble on one device context and stream. (Two or four slices stepped concurrently
-    from their own host threads were tried: +1.5 % at best -- the kernels of the slices slow each other down.)"""
-
-    def __init__(self, prob, device):
-        self.lane = Lane(prob, device)
-
-    def total_iters(self):
-        return self.lane.total_iters()
-
-    def step(self):
-        self.lane.step()
-
     def sync(self):
-        c = self.lane.ctx
-        c._chk(c.H.idahip_sync(c.h), "sync")
+        self.ctx._chk(self.ctx.H.idahip_sync(self.ctx.h), "sync")
 
-    def timing(self, on):
-        self.lane.ctx.timing(on)
-        self.lane.ctx.timing_reset()
+    def timed_steps(self, k, level):
+        """k more rounds with the HIP-event timers at `level` (1: per kernel class, 2: per kernel of the LU)."""
+        if not TIME_ALL:
+            self.ctx.timing(level)
+            self.ctx.timing_reset()
+        for _ in range(k):
+            self.step()
+        self.sync()
+        tim = self.ctx.timing_get()
+        if not TIME_ALL:
+            self.ctx.timing(0)
+        return tim
 
-    def timing_get(self):
-        return self.lane.ctx.timing_get()
+    def whole_pass(self, variant=4, level=0):
+        """SURVEY 8(d): the whole ensemble from fresh state (Ida::new for every system) through its output schedule."""
+        import idahip
+        self.ctx.set_lu_variant(variant)
+        ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
+        self.ctx.timing(level)
+        self.ctx.timing_reset()
+        self.sync()
+        t0 = time.perf_counter()
+        status, _, reached = ens.solve_schedule(self.prob["touts"])
+        self.sync()
+        dt = time.perf_counter() - t0
+        assert (status == 0).all() and (reached == len(self.prob["touts"])).all()
+        tim = self.ctx.timing_get()
+        self.ctx.timing(0)
+        c = ens.counters()
+        out = {"seconds": dt, "iters": ens.total_newton_iters(), "rounds": ens.total_rounds(), "tim": tim,
+               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy()}
+        ens.close()
+        self.ctx.set_lu_variant(4)
+        return out
 
 
 def cpu_baseline(prob_small, cores):
     """The reference's CPU path as restated in oracle/ (kind = "port"), timed on this host's cores on a bounded sample of
-    the same workload: the first len(sample) systems of config 3, integrated t = 0 -> 1 like the GPU run."""
+    the same workload: the first len(sample) systems, integrated over the whole horizon like the GPU run."""
     import oracle_lib as O
     n = prob_small["n"]
     r = O.run_ensemble(prob_small["kind"], n, prob_small["yy0"], prob_small["yp0"], prob_small["rtol"], prob_small["atol"],
@@ -194,50 +208,85 @@ def cpu_baseline(prob_small, cores):
                       % (prob_small["yy0"].shape[0], n, float(prob_small["touts"][-1]), iters, r["seconds"])}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    loaded torch or touched HIP) and leave with the worst of their exit codes. Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+WORKLOADS = {
+    "linear_dense": ("Newton iters/sec (fp64), batched dense DAE N=%d B=%d",
+                     "random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, rtol 1e-6 "
+                     "atol 1e-8, t=0..1 with 10 outputs, every system restarts on its own when it reaches t=1 (endless stream "
+                     "of integrations)"),
+    "heat1d": ("Newton iters/sec (fp64), 1-D heat equation (dense Jacobian) N=%d B=%d",
+               "1-D heat equation by the method of lines, Dirichlet ends algebraic, dense Jacobian (SURVEY 8(d) config 4), N=%d, "
+               "B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 with 10 outputs, every system restarts on its own at the end"),
+    "lorenz63": ("Newton iters/sec (fp64), Lorenz63 as index-0 DAE N=%d B=%d",
+                 "Lorenz63 as an index-0 DAE (SURVEY 8(d) config 2: tests/lorenz63.rs parameters), N=%d, B=%d systems per GPU, rtol "
+                 "1e-6 atol 1e-9, t=0..5 with 50 outputs, every system restarts on its own at the end; launch-latency bound"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=4096, help="systems per GPU")
-    ap.add_argument("--workload", choices=("linear_dense", "heat1d"), default="linear_dense",
-                    help="linear_dense = config 3 (the headline, default N=512 B=4096); heat1d = config 4 (use --n 4096 --batch 256)")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="systems per GPU")
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="linear_dense",
+                    help="linear_dense = config 3 (the headline, N=512 B=4096); heat1d = config 4 (N=4096 B=256); lorenz63 = config 2 (N=3 B=1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip whole_pass and fast_vs_exact (N = 1 extras)")
     args = ap.parse_args()
+    dn, db = {"linear_dense": (512, 4096), "heat1d": (4096, 256), "lorenz63": (3, 1024)}[args.workload]
+    args.n = dn if args.n is None else args.n
+    args.batch = db if args.batch is None else args.batch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
 
-    # ---- inputs: generated before this process touches the GPU (forked worker processes)
-    from idahip import problems
+    # ---- inputs (numpy worker processes of a fork server; nothing of the GPU is loaded yet)
+    from idahip import problems, sharding
     cores = os.cpu_count() or 1
-    procs = int(os.environ.get("IDAHIP_GEN_PROCS", max(1, min(16, cores // max(1, world)))))  # 1 = no fork (use under rocprofv3)
+    procs = int(os.environ.get("IDAHIP_GEN_PROCS", max(1, min(16, cores // max(1, world)))))  # 1 = in-process (use under rocprofv3)
     t0 = time.time()
-    from idahip import sharding
     first, count = sharding.shard_range(rank, world, args.batch)
-    if args.workload == "heat1d":
-        full = problems.heat1d(n=args.n, batch=args.batch * world)  # kappa_b depends on the global system id
-        prob = {k: (v[first:first + count] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
-                for k, v in full.items()}
-    else:
+    if args.workload == "linear_dense":
         prob = problems.linear_dense(n=args.n, batch=count, first=first, procs=procs)
+    else:
+        full = problems.heat1d(n=args.n, batch=args.batch * world) if args.workload == "heat1d" else problems.lorenz63(batch=args.batch * world)
+        prob = {k: (v[first:first + count] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
+                for k, v in full.items()}  # kappa_b / the initial perturbation depend on the global system id
     t_gen = time.time() - t0
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncpu = max(1, min(cores, 64))
-        nsmall = min(args.batch, 16 * ncpu)  # ~10 s of wall time on 64 threads
+        nsmall = min(args.batch, 16 * ncpu if args.workload == "linear_dense" else (ncpu if args.workload == "heat1d" else args.batch))
         small = {k: (v[:nsmall] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == args.batch else v) for k, v in prob.items()}
         cpu = cpu_baseline(small, ncpu)
 
     import torch
     import torch.distributed as dist
-    # Rehearsal knob for a one-GPU box: IDAHIP_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the barrier
-    # and the max-time (RCCL refuses two ranks on one device). Never set by the driver; the JSON line says so.
+    # Rehearsal knob for a one-GPU box: IDAHIP_BENCH_REHEARSE=1 puts every rank on cuda:0 (or on the CPU-side gloo group
+    # only) and uses gloo for the barrier and the max-time (RCCL refuses two ranks on one device). Never set by the driver;
+    # the JSON line says so.
     rehearse = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -258,10 +307,9 @@ def main():
     prob.pop("A", None)  # host copies no longer needed
     prob.pop("B", None)
 
+    # ---- the number: W warm-up steps, then exactly K steps between barriers, no timers inside
     for _ in range(args.warmup):
         run.step()
-    if not TIME_ALL:
-        run.timing(True)
     barrier()
     it0 = run.total_iters()
     t0 = time.perf_counter()
@@ -272,25 +320,87 @@ def main():
     elapsed = time.perf_counter() - t0
     iters = run.total_iters() - it0
     barrier()
-    tim = run.timing_get()
-
     elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cpu" if rehearse else "cuda")
+
+    # ---- untimed repetitions of the same K steps with event timers: per kernel class, then per kernel of the LU
+    tim = run.timed_steps(args.steps, 1)
+    tim2 = run.timed_steps(args.steps, 2)
+
+    extras = None
+    if world == 1 and not args.no_extras:
+        passes = [run.whole_pass(4) for _ in range(3)]
+        rates = [p["iters"] / p["seconds"] for p in passes]
+        fast = run.whole_pass(5, level=1)
+        differ = int((fast["counts"] != passes[0]["counts"]).any(axis=0).sum())
+        rel = float(np.abs(fast["yy"] - passes[0]["yy"]).max() / max(1e-300, np.abs(passes[0]["yy"]).max()))
+        extras = {
+            "whole_pass": {"value": statistics.median(rates), "unit": "Newton iters/s", "passes": [round(r, 1) for r in rates],
+                           "newton_iters_per_pass": passes[0]["iters"], "rounds_per_pass": passes[0]["rounds"],
+                           "seconds_median": statistics.median(p["seconds"] for p in passes),
+                           "protocol": "SURVEY 8(d): every system from fresh state through its whole output schedule, exact LU, "
+                                       "median of 3 passes, wall time of the pass with inputs resident"},
+            "fast_vs_exact": {"fast_whole_pass_value": fast["iters"] / fast["seconds"], "unit": "Newton iters/s",
+                              "systems": int(passes[0]["counts"].shape[1]), "systems_with_different_counts": differ,
+                              "counts_compared": ["nst", "netf", "ncfn", "nni", "nsetups", "kused"],
+                              "max_rel_state_difference": rel,
+                              "lu_plus_solve_fast": lu_plus_solve(fast["tim"], args.n, "fma"),
+                              "note": "fast = idahip_set_lu_variant(5): the LU's updates contracted into FMAs; tolerance stated "
+                                      "and checked in tests/test_gpu_fastlu.py; `value` is measured with the exact LU"},
+        }
 
     if rank == 0:
         ab = algorithmic_bytes(args.n, args.workload)
-        dom = max(("newton_iter", "sys", "sys_jac", "jac", "lu"), key=lambda k: tim[k]["ms"])
-        d = tim[dom]
-        achieved = (ab[dom] * d["systems"]) / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        cls_names = ("newton_iter", "sys", "sys_jac", "jac", "lu", "vector")
+        total_ms = sum(tim[k]["ms"] for k in cls_names)
         classes = {}
-        for k in ("newton_iter", "sys", "sys_jac", "jac", "lu", "vector"):
+        for k in cls_names:
             v = tim[k]
-            ent = {"ms": round(v["ms"], 3), "calls": v["launches"], "systems": v["systems"]}
-            if k in ab and v["ms"] > 0:
+            ent = {"ms": round(v["ms"], 3), "calls": v["launches"], "systems": v["systems"],
+                   "share_of_device_time": round(v["ms"] / total_ms, 4) if total_ms > 0 else None}
+            if ab.get(k) and v["ms"] > 0:
                 ent["GB/s"] = round(ab[k] * v["systems"] / (v["ms"] * 1e-3) / 1e9, 1)
+                ent["frac_of_hbm_peak"] = round(ent["GB/s"] / HBM_PEAK_GBS, 4)
             classes[k] = ent
+        lu_kernels = {}
+        for k in ("lu_panel", "lu_trail", "lu_finalize"):
+            v = tim2[k]
+            lu_kernels[k] = {"ms": round(v["ms"], 3), "launches": v["launches"], "matrix_launches": v["systems"]}
+        # the dominant kernel: by device time among the classes' kernels, with the LU split into its kernels
+        lu_sub_ms = sum(tim2[k]["ms"] for k in ("lu_panel", "lu_trail", "lu_finalize"))
+        scale = tim["lu"]["ms"] / lu_sub_ms if lu_sub_ms > 0 else 0.0  # level-2 pass -> level-1 pass (same work, fewer syncs)
+        cand = {k: tim[k]["ms"] for k in ("newton_iter", "sys", "sys_jac", "jac")}
+        cand.update({k: tim2[k]["ms"] * scale for k in ("lu_panel", "lu_trail", "lu_finalize")})
+        dom = max(cand, key=cand.get)
+        if dom == "lu_trail" and args.n > 8:
+            flops, nbytes, nl = trailing_work(args.n)
+            mats = tim2["lu"]["systems"]                    # matrices factorised in the level-2 pass
+            v = tim2["lu_trail"]
+            tfl = flops * mats / (v["ms"] * 1e-3) / 1e12
+            tr = profiled_traffic("void idahip::lu_trail64w_kernel") if (args.workload == "linear_dense" and args.n == 512) else None
+            roof = {"bound": "valu", "kernel": "lu_trail64w_kernel<1024, false> (rank-64 trailing update + U12 solve of the batched getrf)",
+                    "share_of_device_time": round(cand[dom] / total_ms, 4),
+                    "achieved": round(tfl, 2), "peak": VALU_UNFUSED_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / VALU_UNFUSED_TFLOPS, 4),
+                    "peak_note": "fp64 vector ceiling of the reference's arithmetic: a multiply and a subtract per update (dense.rs:151), "
+                                 "half of the 78.6 TFLOP/s FMA peak at 2.4 GHz; the chip holds about 1.8 GHz in this kernel",
+                    "frac_of_fma_peak": round(tfl / VALU_FMA_TFLOPS, 4),
+                    "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4), "launches": v["launches"],
+                    "algorithmic_flops_per_matrix": flops, "algorithmic_bytes_per_matrix": nbytes,
+                    "hbm_GB/s_on_algorithmic_bytes": round(nbytes * mats / (v["ms"] * 1e-3) / 1e9, 1),
+                    "traffic": None if tr is None else int(tr["hbm_bytes_per_matrix"] * mats / max(1, v["launches"])),
+                    "traffic_bytes_per_matrix": None if tr is None else tr["hbm_bytes_per_matrix"],
+                    "traffic_source": None if tr is None else "%s (rocprofv3 --pmc passes of this command at commit %s)" % (tr["source"], tr["commit"])}
+        else:
+            cls = dom if dom in tim else "lu"
+            d = tim[cls]
+            ach = ab.get(cls, 0) * d["systems"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": {"sys": "linear_sys_kernel<2, false>", "sys_jac": "linear_sys_kernel<2, true>",
+                                               "newton_iter": "newton_iter_kernel<2>", "jac": "linear_jac_kernel"}.get(cls, cls),
+                    "share_of_device_time": round(cand[dom] / total_ms, 4) if total_ms > 0 else None,
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4)}
+        name, wl = WORKLOADS[args.workload]
         out = {
-            "metric": ("Newton iters/sec (fp64), batched dense DAE N=%d B=%d" if args.workload == "linear_dense" else
-                       "Newton iters/sec (fp64), 1-D heat equation (dense Jacobian) N=%d B=%d") % (args.n, args.batch),
+            "metric": name % (args.n, args.batch),
             "value": iters_all / elapsed_max,
             "unit": "Newton iters/s",
             "n_gpus": world,
@@ -302,23 +412,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, "
-                                    "rtol 1e-6 atol 1e-8, t=0..1 with 10 outputs, every system restarts on its own when it reaches "
-                                    "t=1 (endless stream of integrations)" if args.workload == "linear_dense" else
-                                    "1-D heat equation by the method of lines, Dirichlet ends algebraic, dense Jacobian (SURVEY 8(d) "
-                                    "config 4), N=%d, B=%d systems per GPU, rtol 1e-5 atol 1e-8, t=0..0.1 with 10 outputs, every "
-                                    "system restarts on its own at the end") % (args.n, args.batch),
-                       "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
+            "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective"},
             "newton_iters_timed": iters_all,
-            "roofline": roofline(dom, d, ab[dom], achieved, args.n if args.workload == "linear_dense" else -args.n),
+            "roofline": roof,
             "kernel_classes_rank0": classes,
-            "lu_plus_solve": lu_plus_solve(tim, args.n),
+            "lu_kernels_rank0": lu_kernels,
+            "lu_plus_solve": lu_plus_solve(tim, args.n, "unfused") if args.n > 8 else None,
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
         }
+        if extras:
+            out.update(extras)
         if TIME_ALL:
-            out["kernel_classes_cover"] = "every launch of the process (spin-up, warm-up, timed steps)"
+            out["timers"] = "IDAHIP_BENCH_TIME_ALL=1: per-kernel LU timers on in every launch of the process, `value` includes their synchronisations"
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0 over gloo -- not a scaling measurement"
         print(json.dumps(out))

@@ -156,8 +156,16 @@ int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
 typedef enum {
     IDAHIP_K_NEWTON_ITER = 0, IDAHIP_K_SYS = 1, IDAHIP_K_JAC = 2, IDAHIP_K_LU = 3, IDAHIP_K_VECTOR = 4, IDAHIP_K_SOLVE = 5,
     IDAHIP_K_SYS_JAC = 6, /* fused residual + Jacobian pass of idahip_nls_sys_setup */
-    IDAHIP_K_COUNT = 7
+    /* single kernels of the batched LU (timing level 2 only): every launch of the kernel is bracketed by its own pair of
+     * events; `systems` counts matrices x launches */
+    IDAHIP_K_LU_PANEL = 7,    /* lu_wavepanel_kernel (variant 3: lu_panel2_kernel + narrow lu_trail_kernel) */
+    IDAHIP_K_LU_TRAIL = 8,    /* lu_trail64w_kernel */
+    IDAHIP_K_LU_FINALIZE = 9, /* lu_finalize_kernel */
+    IDAHIP_K_COUNT = 10
 } idahip_kclass;
+/* on = 0: no events, no synchronisation (launch counters still run); 1: device time per kernel class (one event pair and
+ * one hipEventSynchronize per class call); 2: additionally per kernel of the LU (which perturbs the class figure of the
+ * LU: use separate passes). */
 int idahip_timing_enable(idahip_ctx* ctx, int on);
 /* accumulated device milliseconds and launch count of a kernel class since the last reset */
 int idahip_timing_get(idahip_ctx* ctx, idahip_kclass k, double* ms, int64_t* launches, int64_t* systems);

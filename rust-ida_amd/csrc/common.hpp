@@ -75,8 +75,8 @@ struct idahip_ctx {
     int next_slot = 0;
 
     // timing
-    bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int timing = 0;  // 0 off, 1 per kernel class, 2 also per kernel of the LU
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double k_ms[IDAHIP_K_COUNT] = {0};
     int64_t k_launches[IDAHIP_K_COUNT] = {0};
     int64_t k_systems[IDAHIP_K_COUNT] = {0};
@@ -194,17 +194,23 @@ struct ArgPack {
 struct KTimer {
     idahip_ctx* c;
     idahip_kclass k;
+    bool on;
+    hipEvent_t e0, e1;
     KTimer(idahip_ctx* ctx, idahip_kclass kc, int nsys) : c(ctx), k(kc) {
+        const bool sub = kc >= IDAHIP_K_LU_PANEL;  // a single kernel inside a class: its own event pair, level 2 only
+        on = sub ? c->timing >= 2 : c->timing >= 1;
+        e0 = sub ? c->ev2 : c->ev0;
+        e1 = sub ? c->ev3 : c->ev1;
         c->k_launches[k] += 1;
         c->k_systems[k] += nsys;
-        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+        if (on) (void)hipEventRecord(e0, c->stream);
     }
     ~KTimer() {
-        if (c->timing) {
-            (void)hipEventRecord(c->ev1, c->stream);
-            (void)hipEventSynchronize(c->ev1);
+        if (on) {
+            (void)hipEventRecord(e1, c->stream);
+            (void)hipEventSynchronize(e1);
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             c->k_ms[k] += (double)ms;
         }
     }

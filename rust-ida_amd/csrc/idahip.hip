@@ -106,7 +106,9 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
         else if (hipMalloc((void**)&c->slots[i].d, c->slot_cap) != hipSuccess) rc = -100;
         else if (hipEventCreateWithFlags(&c->slots[i].done, hipEventDisableTiming) != hipSuccess) rc = -100;
     }
-    if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) rc = -100;
+    if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess ||
+                hipEventCreate(&c->ev3) != hipSuccess))
+        rc = -100;
 
     if (rc) {
         idahip_destroy(c);
@@ -139,6 +141,8 @@ int idahip_destroy(idahip_ctx* c) {
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -767,7 +771,7 @@ int idahip_set_lu_variant(idahip_ctx* c, int variant) {
 int idahip_timing_enable(idahip_ctx* c, int on) {
     DevGuard dev_guard__(c);
     if (!c) return -1;
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     return 0;
 }
 int idahip_timing_get(idahip_ctx* c, idahip_kclass k, double* ms, int64_t* launches, int64_t* systems) {

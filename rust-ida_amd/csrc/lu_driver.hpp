@@ -47,6 +47,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                                        cend, lb * 65);
             }
         } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
+            KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp); the second launch finishes
             // the few systems whose matrices have exact zeros or special values (it returns at once for the others)
             if (fast) {
@@ -59,6 +60,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         } else {
             // two 32-column panels; the first one's update reaches the second through a narrow (32-column) launch of the
             // trailing kernel
+            KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             panel2(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
@@ -68,6 +70,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         }
         const int ntrail = n - k0 - 64;
         if (ntrail > 0) {
+            KTimer kt(c, IDAHIP_K_LU_TRAIL, nsys);
             const int ncb = (ntrail + 63) / 64;
             if (n > LU_MAX_N)
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
@@ -77,8 +80,11 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
         }
     }
-    hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB, n > LU_MAX_N ? 8 : 0,
-                       c->lu_variant >= 4 ? WP_MAX_ROWS : 0);
+    {
+        KTimer kt(c, IDAHIP_K_LU_FINALIZE, nsys);
+        hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB,
+                           n > LU_MAX_N ? 8 : 0, c->lu_variant >= 4 ? WP_MAX_ROWS : 0);
+    }
     return 0;
 }
 

@@ -22,7 +22,7 @@ ROBERTS, LORENZ63, LINEAR_DENSE, HEAT1D = 0, 1, 2, 3
 KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, "heat1d": HEAT1D}
 F_YY, F_YP, F_YYPREDICT, F_YPPREDICT, F_EWT, F_EE, F_DELTA, F_SAVRES, F_PHI0 = range(9)
 K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE, K_SYS_JAC = range(7)
-K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac"]
+K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac", "lu_panel", "lu_trail", "lu_finalize"]
 
 # symbols declared in include/ida_hip.h / include/ida_ensemble.h (checked by tests/test_abi_symbols.py)
 HIP_SYMBOLS = [
