@@ -37,6 +37,7 @@ enum {
     IDAENS_LSETUP_FAIL = -6,
     IDAENS_CLOSE_ROOTS = -10, /* IdaError::CloseRoots (impl_r_check.rs:199) */
     IDAENS_ILL_INPUT = -22,
+    IDAENS_BAD_K = -25,
     IDAENS_BAD_T = -26
 };
 
@@ -92,6 +93,12 @@ int idaens_get_real(const idaens* e, int which, double* out);
 /* get_yy / get_yp: [batch][n] */
 int idaens_get_yy(idaens* e, double* hYY);
 int idaens_get_yp(idaens* e, double* hYP);
+/* Ida::get_dky(t, k, dky) for every system (src/lib.rs:424-529, IDAGetDky): the k-th derivative of the interpolating
+ * polynomial of the last step at t. hDky: [batch][n]; hStatus[batch]: IDAENS_SUCCESS, IDAENS_BAD_K (k > kused of that system)
+ * or IDAENS_BAD_T (t outside the last step), rows of hDky with a bad status are left untouched. The coefficient recurrence
+ * runs here (C IDA's inner-loop bound kused - k + i; the reference's kused - k + 1 agrees for k <= 1, drops terms for
+ * k >= 2 and indexes out of bounds for k = 0, kused = 5 -- SURVEY.md quirk Q9), the sums on the device (idahip_get_dky). */
+int idaens_get_dky(idaens* e, double t, int k, double* hDky, int32_t* hStatus);
 /* totals over the ensemble since creation */
 int64_t idaens_total_newton_iters(const idaens* e);
 int64_t idaens_total_rounds(const idaens* e);

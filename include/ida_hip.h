@@ -133,6 +133,11 @@ int idahip_complete_step(idahip_ctx* ctx, const int32_t* hKused, const double* h
                          int32_t* hEwtBad, const int32_t* hIdx, int nsys);
 int idahip_get_solution(idahip_ctx* ctx, const int32_t* hKord, const double* hCvals, const double* hDvals,
                         const int32_t* hIdx, int nsys);
+/* IDAGetDky (src/lib.rs:424-529), the vector part: hOut[s][0..n) = sum_{j = hKfirst[s] .. hKlast[s]} hCjk[s][j] * phi[j] of
+ * listed system s, accumulated from zero in ascending j (lib.rs:517-526). The coefficients c_j^(k)(t) (lib.rs:464-508) are
+ * the host's (libidaens: idaens_get_dky); 0 <= kfirst <= klast <= 5. hOut is a host array [nsys][n]. */
+int idahip_get_dky(idahip_ctx* ctx, const int32_t* hKfirst, const int32_t* hKlast, const double* hCjk /*[nsys][6]*/, double* hOut,
+                   const int32_t* hIdx, int nsys);
 
 /* Ida::new again for some systems of a running ensemble (src/lib.rs:278-405: phi[0] = yy = y0, phi[1] = yp = y0'):
  * idahip_snapshot_initial keeps a device copy of the current phi[0], phi[1] of every system (call it right after the

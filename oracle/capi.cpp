@@ -203,6 +203,10 @@ int oracle_ida_test_error(void* vh, double ck, double* err_k, double* err_km1) {
 }
 void oracle_ida_complete_step(void* vh, double err_k, double err_km1) { ((Handle*)vh)->ida->complete_step(err_k, err_km1); }
 int oracle_ida_get_solution(void* vh, double t) { return ((Handle*)vh)->ida->get_solution(t); }
+// IDAGetDky (lib.rs:424-529); literal_q9 != 0: the reference's own inner-loop bound, for the cross-check
+int oracle_ida_get_dky(void* vh, double t, int k, double* dky, int literal_q9) {
+    return ((Handle*)vh)->ida->get_dky(t, k, dky, literal_q9 != 0);
+}
 int oracle_ida_nonlinear_solve(void* vh) { return ((Handle*)vh)->ida->nonlinear_solve(); }
 // lsetup seam: evaluate J at the object's current yy/yp/cj and factor it (ida_nls.rs:156-187)
 int oracle_ida_lsetup(void* vh) {

@@ -14,6 +14,7 @@
 //   handle_n_flag               <- /root/reference/src/lib.rs:1120-1244
 //   reset                       <- /root/reference/src/lib.rs:1249-1252
 //   get_solution                <- /root/reference/src/lib.rs:1274-1343
+//   get_dky                     <- /root/reference/src/lib.rs:424-529 (quirk Q9: see the function)
 //   complete_step               <- /root/reference/src/impl_complete_step.rs:22-177
 //   stop_test1 / stop_test2     <- /root/reference/src/impl_stop_test.rs:36-125, 146-211
 //   r_check1/2/3, root_find     <- /root/reference/src/impl_r_check.rs:32-576
@@ -75,6 +76,7 @@ enum IdaStatus {
     IDA_REP_RES_ERR = -9,
     IDA_CONSTR_FAIL = -11,
     IDA_ILL_INPUT = -22,
+    IDA_BAD_K = -25,
     IDA_BAD_T = -26,
     IDA_BAD_TSTOP = -27,
     IDA_CLOSE_ROOTS = -30,
@@ -759,6 +761,57 @@ struct Ida {
             const double* p = phi(j);
             const double dj = ida_dvals[j - 1];
             for (int i = 0; i < n; ++i) yp[i] += dj * p[i];
+        }
+        return IDA_SUCCESS;
+    }
+
+    // ---------------------------------------------------------------- get_dky (lib.rs:424-529, IDAGetDky)
+    // Coefficients c_j^(k)(t) of the k-th derivative of the interpolating polynomial (recurrence of lib.rs:464-508), then
+    // dky = sum_{j=k..kused} c_j^(k) phi_j accumulated from zero in ascending j, product first (lib.rs:517-526: an array of
+    // products, then ndarray's row-by-row sum_axis).
+    // Quirk Q9: the reference bounds the inner loops by `kused - k + 1` where C IDA has `kused - k + i`
+    // (the C line survives as a comment, lib.rs:498,506). For k <= 1 the coefficients that enter the sum are the same; for
+    // k >= 2 the reference leaves c_j^(k) for j > kused - k + 1 at zero and so drops terms of the derivative, and for k = 0
+    // with kused = 5 it indexes cjk[6] out of bounds (a panic). `literal_q9` = true restates the reference loop bound as it is
+    // (clamped to the array) for the cross-check in tests/; the default, which the product mirrors, is the C IDA bound.
+    int get_dky_coeffs(double t, int k, double* cjk, bool literal_q9 = false) const {
+        if (k < 0 || k > ida_kused) return IDA_BAD_K;
+        const double eps = std::numeric_limits<double>::epsilon();
+        const double sgn = (ida_hh > 0.0 || (ida_hh == 0.0 && !std::signbit(ida_hh))) ? 1.0 : -1.0;  // f64::signum
+        const double tfuzz = 100.0 * eps * (std::fabs(nlp.ida_tn) + std::fabs(ida_hh)) * sgn;
+        const double tp = nlp.ida_tn - ida_hused - tfuzz;
+        if ((t - tp) * ida_hh < 0.0) return IDA_BAD_T;
+        double cjk_1[MXORDP1 + 1] = {0.0};
+        double work[MXORDP1 + 1] = {0.0};  // one spare slot: the literal bound writes c[kused + 1] when k = 0
+        const double delt = t - nlp.ida_tn;
+        double psij_1 = 0.0;
+        for (int i = 0; i <= k; ++i) {
+            const double scalar_i = (double)i;
+            if (i == 0) {
+                work[i] = 1.0;
+            } else {
+                work[i] = work[i - 1] * scalar_i / ida_psi[i - 1];
+                psij_1 = ida_psi[i - 1];
+            }
+            int jlast = literal_q9 ? ida_kused - k + 1 : ida_kused - k + i;
+            if (jlast > MXORDP1 - 1) jlast = MXORDP1 - 1;  // (literal bound only: psi has MXORDP1 entries)
+            for (int j = i + 1; j <= jlast; ++j) {
+                work[j] = (scalar_i * cjk_1[j - 1] + work[j - 1] * (delt + psij_1)) / ida_psi[j - 1];
+                psij_1 = ida_psi[j - 1];
+            }
+            for (int j = i + 1; j <= jlast; ++j) cjk_1[j] = work[j];
+        }
+        for (int j = 0; j < MXORDP1; ++j) cjk[j] = work[j];
+        return IDA_SUCCESS;
+    }
+    int get_dky(double t, int k, double* dky, bool literal_q9 = false) const {
+        double cjk[MXORDP1];
+        const int rc = get_dky_coeffs(t, k, cjk, literal_q9);
+        if (rc != IDA_SUCCESS) return rc;
+        for (int i = 0; i < n; ++i) dky[i] = 0.0;
+        for (int j = k; j <= ida_kused; ++j) {
+            const double* p = phi(j);
+            for (int i = 0; i < n; ++i) dky[i] = dky[i] + p[i] * cjk[j];
         }
         return IDA_SUCCESS;
     }

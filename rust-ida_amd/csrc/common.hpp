@@ -60,6 +60,7 @@ struct idahip_ctx {
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr;
     double* lu_l11 = nullptr;
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
+    double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
                          // 5: the same with FMA-contracted updates (`fast`, not bit-identical to the reference)
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512

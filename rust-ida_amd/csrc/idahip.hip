@@ -131,7 +131,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
-                    c->ic_yp};
+                    c->ic_yp, c->dky};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < NSLOT; ++i) {
@@ -724,6 +724,34 @@ int idahip_get_solution(idahip_ctx* c, const int32_t* hKord, const double* hCval
         if ((rc = post_launch(c, "get_solution"))) return rc;
     }
     return ap.finish_async();
+}
+
+int idahip_get_dky(idahip_ctx* c, const int32_t* hKfirst, const int32_t* hKlast, const double* hCjk, double* hOut, const int32_t* hIdx,
+                   int nsys) {
+    DevGuard dev_guard__(c);
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hKfirst || !hKlast || !hCjk || !hOut) return fail(c, -2, "null argument");
+    if (nsys == 0) return 0;
+    for (int s = 0; s < nsys; ++s)
+        if (hKfirst[s] < 0 || hKfirst[s] > hKlast[s] || hKlast[s] >= MXORDP1) return fail(c, -2, "bad derivative range at list position %d", s);
+    const size_t bn = (size_t)c->batch * c->n;
+    if (!c->dky && (rc = dalloc(c, &c->dky, bn))) return rc;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    const int* d_idx = ap.in(hIdx, nsys);
+    const int* d_k0 = ap.in(hKfirst, nsys);
+    const int* d_k1 = ap.in(hKlast, nsys);
+    const double* d_c = ap.in(hCjk, (size_t)MXORDP1 * nsys);
+    if ((rc = ap.upload())) return rc;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, nsys);
+        hipLaunchKernelGGL(get_dky_kernel, dim3(nsys), dim3(256), 0, c->stream, vec_state(c), d_idx, d_k0, d_k1, d_c, c->dky);
+        if ((rc = post_launch(c, "get_dky"))) return rc;
+    }
+    IDAHIP_HIP(c, hipMemcpyAsync(hOut, c->dky, sizeof(double) * (size_t)nsys * c->n, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int idahip_snapshot_initial(idahip_ctx* c) {

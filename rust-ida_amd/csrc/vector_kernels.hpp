@@ -194,6 +194,20 @@ __global__ __launch_bounds__(256) void get_solution_kernel(VecState s, const int
     }
 }
 
+// IDAGetDky (lib.rs:517-526): dky = sum_{j = k .. kused} cjk[j] * phi[j], from zero in ascending j, product then sum
+__global__ __launch_bounds__(256) void get_dky_kernel(VecState s, const int* __restrict__ idx, const int* __restrict__ kfirst,
+                                                      const int* __restrict__ klast, const double* __restrict__ cjk,
+                                                      double* __restrict__ out) {
+    const int b = idx[blockIdx.x];
+    const long vb = (long)b * s.n;
+    const int k0 = kfirst[blockIdx.x], k1 = klast[blockIdx.x];
+    for (int i = threadIdx.x; i < s.n; i += 256) {
+        double d = 0.0;
+        for (int j = k0; j <= k1; ++j) d = d + s.phi[j * s.phistride + vb + i] * cjk[MXORDP1 * blockIdx.x + j];
+        out[(long)blockIdx.x * s.n + i] = d;
+    }
+}
+
 // Ida::new for the listed systems (lib.rs:291-293, ida_nls.rs:83-84): phi[0] = yy = y0, phi[1] = yp = y0'
 __global__ __launch_bounds__(256) void restore_initial_kernel(VecState s, const double* __restrict__ icy, const double* __restrict__ icyp,
                                                               const int* __restrict__ idx) {

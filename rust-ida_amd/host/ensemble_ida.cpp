@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <limits>
 #include <string>
 #include <vector>
@@ -1377,6 +1378,55 @@ int idaens_get_yy(idaens* e, double* hYY) {
 int idaens_get_yp(idaens* e, double* hYP) {
     if (!e) return -1;
     ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_YP, 0, e->batch, hYP));
+    return 0;
+}
+
+// IDAGetDky coefficients c_j^(k)(t) (lib.rs:464-508, recurrence; C IDA's loop bound, see ida_ensemble.h)
+static int get_dky_coeffs(const Sys& s, double t, int k, double* cjk) {
+    if (k < 0 || k > s.kused) return IDAENS_BAD_K;
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double tfuzz = 100.0 * eps * (std::fabs(s.tn) + std::fabs(s.hh)) * signum(s.hh);
+    const double tp = s.tn - s.hused - tfuzz;
+    if ((t - tp) * s.hh < 0.0) return IDAENS_BAD_T;
+    double cjk_1[MXORDP1] = {0.0};
+    for (int j = 0; j < MXORDP1; ++j) cjk[j] = 0.0;
+    const double delt = t - s.tn;
+    double psij_1 = 0.0;
+    for (int i = 0; i <= k; ++i) {
+        const double scalar_i = (double)i;
+        if (i == 0) {
+            cjk[i] = 1.0;
+        } else {
+            cjk[i] = cjk[i - 1] * scalar_i / s.psi[i - 1];
+            psij_1 = s.psi[i - 1];
+        }
+        for (int j = i + 1; j <= s.kused - k + i; ++j) {
+            cjk[j] = (scalar_i * cjk_1[j - 1] + cjk[j - 1] * (delt + psij_1)) / s.psi[j - 1];
+            psij_1 = s.psi[j - 1];
+        }
+        for (int j = i + 1; j <= s.kused - k + i; ++j) cjk_1[j] = cjk[j];
+    }
+    return 0;
+}
+
+int idaens_get_dky(idaens* e, double t, int k, double* hDky, int32_t* hStatus) {
+    if (!e || !hDky || !hStatus) return -1;
+    std::vector<int32_t> idx, k0, k1;
+    std::vector<double> coef;
+    for (int b = 0; b < e->batch; ++b) {
+        double cjk[MXORDP1];
+        hStatus[b] = get_dky_coeffs(e->sys[b], t, k, cjk);
+        if (hStatus[b] != 0) continue;
+        idx.push_back(b);
+        k0.push_back(k);
+        k1.push_back(e->sys[b].kused);
+        coef.insert(coef.end(), cjk, cjk + MXORDP1);
+    }
+    if (idx.empty()) return 0;
+    std::vector<double> out(idx.size() * (size_t)e->n);
+    ENS_CALL(e, idahip_get_dky(e->ctx, k0.data(), k1.data(), coef.data(), out.data(), idx.data(), (int)idx.size()));
+    for (size_t s = 0; s < idx.size(); ++s)
+        std::memcpy(hDky + (size_t)idx[s] * e->n, out.data() + s * e->n, sizeof(double) * e->n);
     return 0;
 }
 

@@ -30,14 +30,14 @@ HIP_SYMBOLS = [
     "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_upload", "idahip_download", "idahip_download_lu",
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
-    "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution",
+    "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_roots",
     "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
-    "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_total_newton_iters",
+    "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
 ]
 
@@ -100,6 +100,7 @@ def load():
     H.idahip_restore.argtypes = [vp, i32p, dp, i32p, ci]
     H.idahip_complete_step.argtypes = [vp, i32p, dp, ci, dp, i32p, i32p, ci]
     H.idahip_get_solution.argtypes = [vp, i32p, dp, dp, i32p, ci]
+    H.idahip_get_dky.argtypes = [vp, i32p, i32p, dp, dp, i32p, ci]
     H.idahip_set_lu_variant.argtypes = [vp, ci]
     H.idahip_timing_enable.argtypes = [vp, ci]
     H.idahip_timing_get.argtypes = [vp, ci, dp, i64p, i64p]
@@ -118,6 +119,7 @@ def load():
     E.idaens_get_counter.argtypes = [vp, ci, i64p]
     E.idaens_get_real.argtypes = [vp, ci, dp]
     E.idaens_get_yy.argtypes = [vp, dp]
+    E.idaens_get_dky.argtypes = [vp, C.c_double, ci, dp, i32p]
     E.idaens_get_yp.argtypes = [vp, dp]
     E.idaens_total_newton_iters.argtypes = [vp]
     E.idaens_total_newton_iters.restype = C.c_int64
@@ -442,6 +444,15 @@ class Ensemble:
         out = np.empty((self.ctx.batch, self.ctx.n))
         assert self.E.idaens_get_yp(self.h, _p(out)) == 0
         return out
+
+    def get_dky(self, t, k):
+        """Ida::get_dky(t, k) for every system -> (status[batch], dky[batch][n]); rows with a bad status are NaN."""
+        out = np.full((self.ctx.batch, self.ctx.n), np.nan)
+        status = np.zeros(self.ctx.batch, dtype=np.int32)
+        rc = self.E.idaens_get_dky(self.h, float(t), int(k), _p(out), _p(status, i32p))
+        if rc < 0:
+            raise IdaHipError("idaens_get_dky failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+        return status, out
 
     def total_newton_iters(self):
         return int(self.E.idaens_total_newton_iters(self.h))

@@ -78,6 +78,8 @@ def lib():
     L.oracle_ida_complete_step.restype = None
     L.oracle_ida_get_solution.argtypes = [C.c_void_p, C.c_double]
     L.oracle_ida_get_solution.restype = C.c_int
+    L.oracle_ida_get_dky.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int]
+    L.oracle_ida_get_dky.restype = C.c_int
     L.oracle_ida_nonlinear_solve.argtypes = [C.c_void_p]
     L.oracle_ida_nonlinear_solve.restype = C.c_int
     L.oracle_ida_lsetup.argtypes = [C.c_void_p]
@@ -170,6 +172,12 @@ class OracleIda:
     def setv(self, name, v):
         v = f64(v).ravel()
         assert self.L.oracle_ida_set_vec(self.h, name.encode(), _ptr(v), v.size) == 0, name
+
+    def get_dky(self, t, k, literal_q9=False):
+        """IDAGetDky (src/lib.rs:424-529) -> (status, dky)."""
+        out = np.zeros(self.n)
+        st = self.L.oracle_ida_get_dky(self.h, float(t), int(k), _ptr(out), int(literal_q9))
+        return st, out
 
     def counters(self):
         return {k: int(self.get(k)) for k in ("nst", "nre", "nje", "nsetups", "nni", "netf", "ncfn", "nge", "n_attempts",

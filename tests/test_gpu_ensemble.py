@@ -368,3 +368,40 @@ def test_streaming_restarts_reproduce_fresh_integrations():
     assert ens.total_rounds() == rounds
     # every completed integration contributed its full Newton count, the running ones their partial counts
     assert ens.total_newton_iters() >= 3 * full_nni.min() * B // 2
+
+
+@pytest.mark.parametrize("kind", ["linear_dense", "lorenz63"])
+def test_get_dky_matches_the_oracle(kind):
+    """Ida::get_dky (src/lib.rs:424-529) for every system and every k = 0 .. kused: coefficients on the host (libidaens), sums
+    on the device (idahip_get_dky); bit-identical to the oracle's restatement, argument checks included."""
+    import idahip
+    from idahip import problems
+    p = problems.linear_dense(n=48, batch=7) if kind == "linear_dense" else problems.lorenz63(batch=40)
+    touts = [float(t) for t in p["touts"][:3]]
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    for t in touts:
+        status, _ = ens.solve(t)
+        assert (status == 0).all()
+    B, n = p["yy0"].shape
+    tn, hused, kused = ens.real("tn"), ens.real("hused"), ens.counter("kused")
+    oracles = []
+    for s in range(B):
+        kw = {"params": p["params"][s]} if kind == "lorenz63" else {"A": p["A"][s], "B": p["B"][s], "c": p["c"][s]}
+        o = O.OracleIda(kind, n, p["yy0"][s], p["yp0"][s], p["rtol"], p["atol"], **kw)
+        for t in touts:
+            assert o.solve(t)[0] == 0
+        assert o.get("tn") == tn[s] and int(o.get("kused")) == kused[s]
+        oracles.append(o)
+    t = touts[-1] - 0.37 * hused.min()  # inside the last step of every system (all have stepped past touts[-1])
+    for k in range(0, int(kused.max()) + 2):
+        status, dky = ens.get_dky(t, k)
+        for s in range(B):
+            st_o, d_o = oracles[s].get_dky(t, k)
+            assert status[s] == st_o, (k, s)
+            if st_o == 0:
+                assert np.array_equal(dky[s], d_o), (k, s)
+            else:
+                assert st_o == -25 and k > kused[s] and np.isnan(dky[s]).all()
+    status, _ = ens.get_dky(float(tn.min() - 3.0 * hused.max()), 0)   # before the last step of every system
+    assert (status == -26).all()
+    ens.close()
