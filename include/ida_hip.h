@@ -35,8 +35,21 @@ typedef enum {
     IDAHIP_ROBERTS = 0,      /* src/sample_problems/roberts.rs:47-91                                  (n = 3) */
     IDAHIP_LORENZ63 = 1,     /* tests/lorenz63.rs:17-25,47-53; params [p, r, b] per system            (n = 3) */
     IDAHIP_LINEAR_DENSE = 2, /* F = A y' + B y - c, A/B dense column-major per system */
-    IDAHIP_HEAT1D = 3        /* 1-D heat, method of lines; params [kappa/dx^2] per system (config 4)           */
+    IDAHIP_HEAT1D = 3,       /* 1-D heat, method of lines; params [kappa/dx^2] per system (config 4)           */
+    IDAHIP_HOST_CALLBACK = 4 /* any IdaProblem: res / jac are host functions (idahip_set_host_problem); slow path   */
 } idahip_problem;
+
+/* The user problem of kind IDAHIP_HOST_CALLBACK: Residual::res and Jacobian::jac of src/traits.rs:12-70 as C callbacks, called on
+ * the host for one listed system at a time (`sys` = its index in the batch, `user` = the pointer given at registration).
+ *   res: resval[0..n) = F(tt, yy, yp)                                                       (traits.rs:28-37)
+ *   jac: J = dF/dy + cj dF/dy', written column-major (J[j * n + i] = row i, column j) into a matrix the library has zeroed,
+ *        as idaLsSetup does (src/ida_ls.rs:255); resvec is the residual at (yy, yp)        (traits.rs:58-69)
+ * A nonzero return aborts the call that triggered it (it returns -7). Everything else -- batched LU, triangular solves,
+ * norms, the stepper's vectors -- runs on the device as for the built-in problems; y, y' and the residual cross PCIe once
+ * per evaluation, the Jacobian once per linear setup. */
+typedef int (*idahip_res_fn)(int sys, double tt, const double* yy, const double* yp, double* resval, void* user);
+typedef int (*idahip_jac_fn)(int sys, double tt, double cj, const double* yy, const double* yp, const double* resvec, double* J,
+                             void* user);
 
 /* ctx-resident vectors of the reference's IdaNLProblem / Ida structs (src/ida_nls.rs:27-59, src/lib.rs:104-126) */
 typedef enum {
@@ -66,6 +79,8 @@ int idahip_set_tolerances(idahip_ctx* ctx, double rtol, const double* hAtol, int
 int idahip_set_problem_params(idahip_ctx* ctx, int first, int count, const double* hParams, int nparam);
 /* LINEAR_DENSE data, systems [first, first+count): hA, hB [count][n*n] column-major, hC [count][n] */
 int idahip_set_linear_dense(idahip_ctx* ctx, int first, int count, const double* hA, const double* hB, const double* hC);
+/* IDAHIP_HOST_CALLBACK: the problem's callbacks (both required) and the pointer handed back to them */
+int idahip_set_host_problem(idahip_ctx* ctx, idahip_res_fn res, idahip_jac_fn jac, void* user);
 /* state movement: field of systems [first, first+count) <-> host [count][n] */
 int idahip_upload(idahip_ctx* ctx, idahip_field f, int first, int count, const double* h);
 int idahip_download(idahip_ctx* ctx, idahip_field f, int first, int count, double* h);

@@ -69,6 +69,11 @@ struct idahip_ctx {
     double* params = nullptr;  // [batch][nparam]
     int nparam = 0;
     double *A = nullptr, *B = nullptr, *C = nullptr;  // LINEAR_DENSE
+    idahip_res_fn cb_res = nullptr;                   // HOST_CALLBACK
+    idahip_jac_fn cb_jac = nullptr;
+    void* cb_user = nullptr;
+    double* cb_stage = nullptr;                       // [batch][3][n] device staging of yy, yp, res of the listed systems
+    std::vector<double> cb_host;                      // host mirror of cb_stage, and the Jacobian of one system
 
     // staging ring
     idahip::Slot slots[idahip::NSLOT];

@@ -68,6 +68,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (!out) return -1;
     *out = nullptr;
     if (n < 1 || batch < 1) return -2;
+    if ((int)kind < 0 || (int)kind > (int)IDAHIP_HOST_CALLBACK) return -2;
     if ((kind == IDAHIP_ROBERTS || kind == IDAHIP_LORENZ63) && n != 3) return -2;
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
@@ -100,6 +101,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     }
     if (kind == IDAHIP_LORENZ63) { c->nparam = 3; rc |= dalloc(c, &c->params, (size_t)batch * 3); }
     if (kind == IDAHIP_HEAT1D) { c->nparam = 1; rc |= dalloc(c, &c->params, (size_t)batch); }
+    if (kind == IDAHIP_HOST_CALLBACK) rc |= dalloc(c, &c->cb_stage, 3 * bn);
     c->slot_cap = (size_t)batch * 256 + 4096;  // per call: <= ~110 B of scalars per system (predict) + list ids + results
     for (int i = 0; i < NSLOT && !rc; ++i) {
         if (hipHostMalloc((void**)&c->slots[i].h, c->slot_cap) != hipSuccess) rc = -100;
@@ -131,7 +133,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
-                    c->ic_yp, c->dky};
+                    c->ic_yp, c->dky, c->cb_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < NSLOT; ++i) {
@@ -193,6 +195,15 @@ int idahip_set_linear_dense(idahip_ctx* c, int first, int count, const double* h
     IDAHIP_HIP(c, hipMemcpy(c->A + first * nn, hA, sizeof(double) * count * nn, hipMemcpyHostToDevice));
     IDAHIP_HIP(c, hipMemcpy(c->B + first * nn, hB, sizeof(double) * count * nn, hipMemcpyHostToDevice));
     IDAHIP_HIP(c, hipMemcpy(c->C + (size_t)first * c->n, hC, sizeof(double) * count * c->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int idahip_set_host_problem(idahip_ctx* c, idahip_res_fn res, idahip_jac_fn jac, void* user) {
+    if (!c || !res || !jac) return -1;
+    if (c->kind != IDAHIP_HOST_CALLBACK) return fail(c, -2, "not an IDAHIP_HOST_CALLBACK ctx");
+    c->cb_res = res;
+    c->cb_jac = jac;
+    c->cb_user = user;
     return 0;
 }
 
@@ -358,9 +369,56 @@ int idahip_wrms(idahip_ctx* c, const double* dX, const double* dW, double* hOut,
 namespace {
 
 // residual kernels of IdaNLProblem::sys; jac_out != nullptr (linear dense, column-major work matrix only) also forms J
-int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out) {
+// residual of a host-callback problem: device forms and packs yy, yp; host calls the user's res per listed system; device
+// scatters the residuals (launch_sys with c->kind == IDAHIP_HOST_CALLBACK)
+int callback_sys(idahip_ctx* c, const SysArgs& a, const double* hTn, const int32_t* hIdx, int nsys) {
+    const int n = c->n;
+    if (!c->cb_res || !c->cb_jac) return fail(c, -2, "IDAHIP_HOST_CALLBACK: idahip_set_host_problem has not been called");
+    const size_t cnt = (size_t)nsys * 3 * n;
+    hipLaunchKernelGGL(callback_pre_kernel, dim3(nsys), dim3(256), 0, c->stream, a, c->cb_stage);
+    if (c->cb_host.size() < cnt) c->cb_host.resize(cnt);
+    double* h = c->cb_host.data();
+    IDAHIP_HIP(c, hipMemcpyAsync(h, c->cb_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < nsys; ++s) {
+        double* hs = h + (size_t)s * 3 * n;
+        if (c->cb_res(hIdx[s], hTn[s], hs, hs + n, hs + 2 * n, c->cb_user) != 0)
+            return fail(c, -7, "the user's residual function failed for system %d", hIdx[s]);
+    }
+    IDAHIP_HIP(c, hipMemcpyAsync(c->cb_stage, h, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(callback_post_kernel, dim3(nsys), dim3(256), 0, c->stream, a, (const double*)c->cb_stage);
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));  // cb_host is reused by the next call
+    return post_launch(c, "nls_sys (host callback)");
+}
+
+// Jacobian of a host-callback problem into the LU work matrices (column-major per system)
+int callback_jac(idahip_ctx* c, double* work, const int* d_idx, const double* hTn, const double* hCj, const int32_t* hIdx, int nsys) {
+    const int n = c->n;
+    const size_t nn = (size_t)n * n;
+    if (!c->cb_res || !c->cb_jac) return fail(c, -2, "IDAHIP_HOST_CALLBACK: idahip_set_host_problem has not been called");
+    const size_t cnt = (size_t)nsys * 3 * n;
+    hipLaunchKernelGGL(callback_pack_kernel, dim3(nsys), dim3(256), 0, c->stream, (const double*)c->yy, (const double*)c->yp,
+                       (const double*)c->savres, d_idx, n, c->cb_stage);
+    if (c->cb_host.size() < cnt + nn) c->cb_host.resize(cnt + nn);
+    double* h = c->cb_host.data();
+    double* J = h + cnt;
+    IDAHIP_HIP(c, hipMemcpyAsync(h, c->cb_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < nsys; ++s) {
+        const double* hs = h + (size_t)s * 3 * n;
+        for (size_t e = 0; e < nn; ++e) J[e] = 0.0;  // J <- 0 (ida_ls.rs:255)
+        if (c->cb_jac(hIdx[s], hTn[s], hCj[s], hs, hs + n, hs + 2 * n, J, c->cb_user) != 0)
+            return fail(c, -7, "the user's Jacobian function failed for system %d", hIdx[s]);
+        IDAHIP_HIP(c, hipMemcpy(work + (size_t)hIdx[s] * nn, J, sizeof(double) * nn, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out, const double* hTn = nullptr, const int32_t* hIdx = nullptr) {
     const int n = c->n;
     switch (c->kind) {
+        case IDAHIP_HOST_CALLBACK:
+            return callback_sys(c, a, hTn, hIdx, nsys);
         case IDAHIP_ROBERTS:
             hipLaunchKernelGGL(tiny_sys_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, a, (const double*)nullptr, 0, nsys);
             break;
@@ -387,10 +445,13 @@ int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out) {
 }
 
 // Jacobian kernels of IdaNLProblem::setup (jac at the current yy, yp, cj) into the LU work matrix
-int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj, int nsys) {
+int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj, int nsys, const double* hTn = nullptr,
+               const double* hCj = nullptr, const int32_t* hIdx = nullptr) {
     const int n = c->n;
     const long nn = (long)n * n;
     switch (c->kind) {
+        case IDAHIP_HOST_CALLBACK:
+            return callback_jac(c, work, d_idx, hTn, hCj, hIdx, nsys);
         case IDAHIP_ROBERTS:
             hipLaunchKernelGGL(tiny_jac_kernel<IDAHIP_ROBERTS>, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, work, (const double*)c->yy,
                                (const double*)nullptr, 0, d_idx, d_cj, nsys);
@@ -461,7 +522,7 @@ int idahip_nls_sys(idahip_ctx* c, const double* hTn, const double* hCj, int rese
     fill_sys_args(c, a, reset_ee);
     {
         KTimer kt(c, IDAHIP_K_SYS, nsys);
-        if ((rc = launch_sys(c, a, nsys, nullptr))) return rc;
+        if ((rc = launch_sys(c, a, nsys, nullptr, hTn, hIdx))) return rc;
     }
     return ap.finish_async();
 }
@@ -481,7 +542,7 @@ int idahip_nls_lsetup(idahip_ctx* c, const double* hTn, const double* hCj, int32
     double* work = (n <= TINY_N) ? c->lu : c->jw;
     {
         KTimer kt(c, IDAHIP_K_JAC, nsys);
-        if ((rc = launch_jac(c, work, d_idx, d_cj, nsys))) return rc;
+        if ((rc = launch_jac(c, work, d_idx, d_cj, nsys, hTn, hCj, hIdx))) return rc;
     }
     return factor_and_report(c, work, d_idx, hIdx, nsys, hInfo);
 }
@@ -507,11 +568,11 @@ int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, in
     const bool fused = c->kind == IDAHIP_LINEAR_DENSE && n > TINY_N;
     {
         KTimer kt(c, fused ? IDAHIP_K_SYS_JAC : IDAHIP_K_SYS, nsys);
-        if ((rc = launch_sys(c, a, nsys, fused ? work : nullptr))) return rc;
+        if ((rc = launch_sys(c, a, nsys, fused ? work : nullptr, hTn, hIdx))) return rc;
     }
     if (!fused) {
         KTimer kt(c, IDAHIP_K_JAC, nsys);
-        if ((rc = launch_jac(c, work, a.idx, a.cj, nsys))) return rc;
+        if ((rc = launch_jac(c, work, a.idx, a.cj, nsys, hTn, hCj, hIdx))) return rc;
     }
     return factor_and_report(c, work, a.idx, hIdx, nsys, hInfo);
 }

@@ -277,4 +277,51 @@ __global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats
     }
 }
 
+// ------------------------------------------------------------------------------------------------ host-callback problems
+// idaNlsResidual around a user residual that lives on the host (ida_nls.rs:118-153): `pre` forms yy, yp on the device and
+// packs them for the listed systems, the host evaluates F, `post` scatters the residuals into delta and savres.
+__global__ __launch_bounds__(256) void callback_pre_kernel(SysArgs a, double* __restrict__ stage) {
+    const int n = a.n;
+    const int b = a.idx[blockIdx.x];
+    const long vb = (long)b * n;
+    const double cj = a.cj[blockIdx.x];
+    double* __restrict__ sy = stage + (long)blockIdx.x * 3 * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double yc = a.ee[vb + i];
+        if (a.reset_ee) {
+            yc = 0.0;
+            a.ee[vb + i] = 0.0;
+        }
+        const double y = a.yypredict[vb + i] + yc;
+        const double yp = a.yppredict[vb + i] + cj * yc;
+        a.yy[vb + i] = y;
+        a.yp[vb + i] = yp;
+        sy[i] = y;
+        sy[n + i] = yp;
+    }
+}
+__global__ __launch_bounds__(256) void callback_post_kernel(SysArgs a, const double* __restrict__ stage) {
+    const int n = a.n;
+    const int b = a.idx[blockIdx.x];
+    const long vb = (long)b * n;
+    const double* __restrict__ r = stage + (long)blockIdx.x * 3 * n + 2 * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a.delta[vb + i] = r[i];
+        a.savres[vb + i] = r[i];
+    }
+}
+// current yy, yp, savres of the listed systems, packed for the user's jac
+__global__ __launch_bounds__(256) void callback_pack_kernel(const double* __restrict__ yy, const double* __restrict__ yp,
+                                                            const double* __restrict__ res, const int* __restrict__ idx, int n,
+                                                            double* __restrict__ stage) {
+    const int b = idx[blockIdx.x];
+    const long vb = (long)b * n;
+    double* __restrict__ sy = stage + (long)blockIdx.x * 3 * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        sy[i] = yy[vb + i];
+        sy[n + i] = yp[vb + i];
+        sy[2 * n + i] = res[vb + i];
+    }
+}
+
 }  // namespace idahip

@@ -18,8 +18,11 @@ dp = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 
-ROBERTS, LORENZ63, LINEAR_DENSE, HEAT1D = 0, 1, 2, 3
-KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, "heat1d": HEAT1D}
+ROBERTS, LORENZ63, LINEAR_DENSE, HEAT1D, HOST_CALLBACK = 0, 1, 2, 3, 4
+KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, "heat1d": HEAT1D, "host_callback": HOST_CALLBACK}
+RES_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+JAC_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                     C.POINTER(C.c_double), C.c_void_p)
 F_YY, F_YP, F_YYPREDICT, F_YPPREDICT, F_EWT, F_EE, F_DELTA, F_SAVRES, F_PHI0 = range(9)
 K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE, K_SYS_JAC = range(7)
 K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac", "lu_panel", "lu_trail", "lu_finalize"]
@@ -27,7 +30,7 @@ K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac", "lu_
 # symbols declared in include/ida_hip.h / include/ida_ensemble.h (checked by tests/test_abi_symbols.py)
 HIP_SYMBOLS = [
     "idahip_create", "idahip_destroy", "idahip_last_error", "idahip_sync", "idahip_n", "idahip_batch", "idahip_set_tolerances",
-    "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_upload", "idahip_download", "idahip_download_lu",
+    "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_set_host_problem", "idahip_upload", "idahip_download", "idahip_download_lu",
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
@@ -102,6 +105,7 @@ def load():
     H.idahip_get_solution.argtypes = [vp, i32p, dp, dp, i32p, ci]
     H.idahip_get_dky.argtypes = [vp, i32p, i32p, dp, dp, i32p, ci]
     H.idahip_set_lu_variant.argtypes = [vp, ci]
+    H.idahip_set_host_problem.argtypes = [vp, RES_FN, JAC_FN, vp]
     H.idahip_timing_enable.argtypes = [vp, ci]
     H.idahip_timing_get.argtypes = [vp, ci, dp, i64p, i64p]
     H.idahip_timing_reset.argtypes = [vp]
@@ -182,6 +186,33 @@ class Ctx:
         """A, B: [count][n][n] stored column-major per system, i.e. A[s, j, i] = A_s(i, j); c: [count][n]."""
         A, B, c = _f64(A), _f64(B), _f64(c)
         self._chk(self.H.idahip_set_linear_dense(self.h, first, A.shape[0], _p(A), _p(B), _p(c)), "set_linear_dense")
+
+    def set_host_problem(self, res, jac):
+        """IDAHIP_HOST_CALLBACK: res(sys, t, yy, yp) -> residual vector; jac(sys, t, cj, yy, yp, res) -> J[n][n] (row, col), or
+        None entries left zero. Python callables are wrapped into the C callbacks of include/ida_hip.h."""
+        n = self.n
+
+        def c_res(sys, t, yy, yp, out, _user):
+            try:
+                r = res(sys, t, np.ctypeslib.as_array(yy, (n,)), np.ctypeslib.as_array(yp, (n,)))
+                for i in range(n):
+                    out[i] = r[i]
+                return 0
+            except Exception:  # an exception must not cross the C boundary
+                return 1
+
+        def c_jac(sys, t, cj, yy, yp, rv, J, _user):
+            try:
+                m = jac(sys, t, cj, np.ctypeslib.as_array(yy, (n,)), np.ctypeslib.as_array(yp, (n,)), np.ctypeslib.as_array(rv, (n,)))
+                for i in range(n):
+                    for j in range(n):
+                        J[j * n + i] = m[i][j]  # column-major
+                return 0
+            except Exception:
+                return 1
+
+        self._cb = (RES_FN(c_res), JAC_FN(c_jac))  # keep the thunks alive as long as the ctx
+        self._chk(self.H.idahip_set_host_problem(self.h, self._cb[0], self._cb[1], None), "set_host_problem")
 
     def upload(self, field, arr, first=0):
         a = _f64(arr).reshape(-1, self.n)

@@ -179,6 +179,8 @@ def make_ctx(prob, device=0, stream=None):
         step = max(1, (1 << 28) // (8 * prob["n"] * prob["n"]))  # <= 256 MiB per matrix upload
         for f in range(0, batch, step):
             ctx.set_linear_dense(prob["A"][f:f + step], prob["B"][f:f + step], prob["c"][f:f + step], first=f)
+    elif prob["kind"] == "host_callback":
+        ctx.set_host_problem(prob["res"], prob["jac"])
     elif "params" in prob:
         ctx.set_problem_params(prob["params"])
     return ctx

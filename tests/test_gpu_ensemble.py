@@ -405,3 +405,49 @@ def test_get_dky_matches_the_oracle(kind):
     status, _ = ens.get_dky(float(tn.min() - 3.0 * hused.max()), 0)   # before the last step of every system
     assert (status == -26).all()
     ens.close()
+
+
+def test_user_problem_through_host_callbacks_reproduces_the_roberts_example():
+    """IDAHIP_HOST_CALLBACK: an arbitrary `IdaProblem` (src/traits.rs:12-70,92-94) whose res / jac are host functions. Roberts
+    written as such callbacks (operation order of src/sample_problems/roberts.rs:47-91) runs the reference's example --
+    12 outputs, two root functions -- with every return equal to the built-in device kernels' (i.e. the oracle's), and ends
+    with the reference's figures: 362 steps, 377 attempts, 537 Newton iterations, the y(4e10) bits of SURVEY.md appendix A."""
+    import idahip
+    from idahip import problems
+    R = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "roberts_example.json")))
+
+    def res(sys, t, y, yp):
+        r0 = -0.04 * y[0] + 1.0e4 * y[1] * y[2]
+        r1 = -r0 - 3.0e7 * y[1] * y[1] - yp[1]
+        r0 -= yp[0]
+        return [r0, r1, y[0] + y[1] + y[2] - 1.0]
+
+    def jac(sys, t, cj, y, yp, r):
+        return [[-0.04 - cj, 1.0e4 * y[2], 1.0e4 * y[1]],
+                [0.04, -1.0e4 * y[2] - 6.0e7 * y[1] - cj, -1.0e4 * y[1]],
+                [1.0, 1.0, 1.0]]
+
+    B = 2
+    p = {"kind": "host_callback", "n": 3, "yy0": np.tile(R["yy0"], (B, 1)), "yp0": np.tile(R["yp0"], (B, 1)), "rtol": R["rtol"],
+         "atol": np.array(R["atol"]), "res": res, "jac": jac}
+    ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    ens.set_roots([0, 2], [0.0001, 0.01])
+    ida = O.OracleIda("roberts", 3, R["yy0"], R["yp0"], R["rtol"], R["atol"])
+    tout, iout, nroot_returns = R["tout0"], 0, 0
+    while iout < R["nout"]:
+        st_o, tret_o = ida.solve(tout)
+        st, tret = ens.solve(tout)
+        assert (st == st_o).all() and st_o >= 0
+        assert np.array_equal(tret, np.full(B, tret_o))
+        assert np.array_equal(ens.yy(), np.tile(ida.getv("yy"), (B, 1)))
+        if st_o == 2:
+            nroot_returns += 1
+        else:
+            iout += 1
+            tout *= R["tout_factor"]
+    assert nroot_returns == 2
+    c = ens.counters()
+    assert (c["nst"] == 362).all() and (c["n_attempts"] == 377).all() and (c["nni"] == 537).all() and (c["netf"] == 15).all()
+    y_end = ens.yy()[0]
+    assert [float.hex(float(v)) for v in y_end] == ["0x1.a1d277a766cb0p-25", "0x1.b61e4814ea4bbp-43", "0x1.fffffe5e2d1adp-1"]
+    ens.close()
