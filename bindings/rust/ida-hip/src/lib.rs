@@ -1,0 +1,472 @@
+//! rust-ida's solver traits on MI355X.
+//!
+//! * [`HipDense`] implements `linear::LSolver<f64, D>` (crates/linear/src/traits.rs:27-91) with the batched LU and
+//!   triangular solves of libidahip at batch = 1: `setup` = `dense_get_rf` (dense.rs:86-158), `solve` = `dense_get_rs`
+//!   (dense.rs:165-206), bit-identical factors, pivots and solutions.
+//! * [`HipEnsemble`] is the batched counterpart of `Ida`: B independent IVPs stepped in lock-step rounds by libidaens, each
+//!   system taking exactly the steps the reference's `Ida::solve` takes for it (same step sizes, orders, counters, bits).
+//! * [`HostProblem`] carries any `IdaProblem`-style residual / Jacobian pair (src/traits.rs:12-70) across the C ABI as
+//!   host callbacks (problem kind `IDAHIP_HOST_CALLBACK`); the four built-in device problems are selected by [`Problem`].
+//!
+//! Errors follow the reference: `linear::Error::LUFactFail { col }` with the 1-based column (dense.rs:121) for a zero pivot;
+//! anything else the library reports (< 0: bad argument, HIP failure) is a programming or environment error and surfaces
+//! as [`Error::Library`] with the library's message. Nothing unwinds across the FFI: a panic inside a user callback is
+//! caught and turned into a failed call.
+use std::ffi::CStr;
+use std::marker::PhantomData;
+use std::os::raw::{c_double, c_int, c_void};
+use std::panic::{catch_unwind, AssertUnwindSafe};
+use std::ptr;
+
+use ida_hip_sys as sys;
+use linear::{LSolver, LSolverType};
+use nalgebra::{allocator::Allocator, DefaultAllocator, DimName, Matrix, StorageMut, U1};
+
+/// Failure of a library call.
+#[derive(Debug)]
+pub enum Error {
+    /// `linear::Error::LUFactFail` of one or more systems (1-based column, dense.rs:121), by system index.
+    Singular(Vec<(usize, usize)>),
+    /// The library refused the call or the device failed (`idahip_last_error` / `idaens_last_error`).
+    Library { code: i32, message: String },
+}
+
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        match self {
+            Error::Singular(v) => write!(f, "singular matrix in LU factorisation (system, column): {:?}", v),
+            Error::Library { code, message } => write!(f, "libidahip error {}: {}", code, message),
+        }
+    }
+}
+impl std::error::Error for Error {}
+
+/// The problem a context integrates (`idahip_problem`).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Problem {
+    /// src/sample_problems/roberts.rs (n = 3)
+    Roberts,
+    /// tests/lorenz63.rs parameters, index-0 DAE (n = 3); parameters [p, r, b] per system
+    Lorenz63,
+    /// F = A y' + B y - c with dense A, B per system (column-major)
+    LinearDense,
+    /// 1-D heat equation by the method of lines; parameter kappa / dx^2 per system
+    Heat1D,
+    /// any residual / Jacobian pair evaluated on the host ([`HostProblem`])
+    HostCallback,
+}
+
+impl Problem {
+    fn code(self) -> c_int {
+        match self {
+            Problem::Roberts => sys::IDAHIP_ROBERTS,
+            Problem::Lorenz63 => sys::IDAHIP_LORENZ63,
+            Problem::LinearDense => sys::IDAHIP_LINEAR_DENSE,
+            Problem::Heat1D => sys::IDAHIP_HEAT1D,
+            Problem::HostCallback => sys::IDAHIP_HOST_CALLBACK,
+        }
+    }
+}
+
+/// Residual and Jacobian of a user problem, evaluated on the host for one system at a time
+/// (`Residual::res`, `Jacobian::jac`: src/traits.rs:28-37, 58-69). `jac` receives a zeroed column-major n x n matrix.
+pub trait HostProblem {
+    fn res(&self, sys: usize, tt: f64, yy: &[f64], yp: &[f64], resval: &mut [f64]);
+    fn jac(&self, sys: usize, tt: f64, cj: f64, yy: &[f64], yp: &[f64], resvec: &[f64], jac_colmajor: &mut [f64]);
+}
+
+struct CallbackBox {
+    n: usize,
+    problem: Box<dyn HostProblem>,
+}
+
+unsafe extern "C" fn res_trampoline(s: c_int, tt: c_double, yy: *const c_double, yp: *const c_double, r: *mut c_double, user: *mut c_void) -> c_int {
+    let cb = &*(user as *const CallbackBox);
+    let n = cb.n;
+    let out = catch_unwind(AssertUnwindSafe(|| {
+        cb.problem.res(
+            s as usize,
+            tt,
+            std::slice::from_raw_parts(yy, n),
+            std::slice::from_raw_parts(yp, n),
+            std::slice::from_raw_parts_mut(r, n),
+        )
+    }));
+    if out.is_ok() {
+        0
+    } else {
+        1
+    }
+}
+
+unsafe extern "C" fn jac_trampoline(
+    s: c_int,
+    tt: c_double,
+    cj: c_double,
+    yy: *const c_double,
+    yp: *const c_double,
+    rv: *const c_double,
+    j: *mut c_double,
+    user: *mut c_void,
+) -> c_int {
+    let cb = &*(user as *const CallbackBox);
+    let n = cb.n;
+    let out = catch_unwind(AssertUnwindSafe(|| {
+        cb.problem.jac(
+            s as usize,
+            tt,
+            cj,
+            std::slice::from_raw_parts(yy, n),
+            std::slice::from_raw_parts(yp, n),
+            std::slice::from_raw_parts(rv, n),
+            std::slice::from_raw_parts_mut(j, n * n),
+        )
+    }));
+    if out.is_ok() {
+        0
+    } else {
+        1
+    }
+}
+
+/// One device context: all device memory of an ensemble of `batch` systems of size `n` (RAII over `idahip_create`).
+pub struct Ctx {
+    raw: *mut sys::idahip_ctx,
+    n: usize,
+    batch: usize,
+    callbacks: Option<Box<CallbackBox>>,
+}
+
+// A ctx may move between threads; every method takes `&mut self` like the reference's solver objects, so it is not Sync.
+unsafe impl Send for Ctx {}
+
+impl Ctx {
+    pub fn new(device: i32, n: usize, batch: usize, problem: Problem) -> Result<Self, Error> {
+        let mut raw: *mut sys::idahip_ctx = ptr::null_mut();
+        let rc = unsafe { sys::idahip_create(&mut raw, device, n as c_int, batch as c_int, problem.code(), ptr::null_mut()) };
+        if rc != 0 || raw.is_null() {
+            return Err(Error::Library { code: rc, message: "idahip_create failed (no GPU visible, or bad size)".to_string() });
+        }
+        Ok(Ctx { raw, n, batch, callbacks: None })
+    }
+
+    pub fn n(&self) -> usize {
+        self.n
+    }
+    pub fn batch(&self) -> usize {
+        self.batch
+    }
+    pub fn as_raw(&mut self) -> *mut sys::idahip_ctx {
+        self.raw
+    }
+
+    fn last_error(&self) -> String {
+        unsafe { CStr::from_ptr(sys::idahip_last_error(self.raw)).to_string_lossy().into_owned() }
+    }
+    fn check(&self, rc: c_int) -> Result<c_int, Error> {
+        if rc < 0 {
+            Err(Error::Library { code: rc, message: self.last_error() })
+        } else {
+            Ok(rc)
+        }
+    }
+
+    /// `TolControlSS` / `TolControlSV` (src/tol_control.rs): one absolute tolerance, or one per component.
+    pub fn set_tolerances(&mut self, rtol: f64, atol: &[f64]) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_set_tolerances(self.raw, rtol, atol.as_ptr(), atol.len() as c_int) };
+        self.check(rc).map(|_| ())
+    }
+
+    /// Matrices and right-hand sides of systems `first .. first + count` of a [`Problem::LinearDense`] context
+    /// (column-major per system).
+    pub fn set_linear_dense(&mut self, first: usize, a: &[f64], b: &[f64], c: &[f64]) -> Result<(), Error> {
+        let nn = self.n * self.n;
+        assert!(a.len() == b.len() && a.len() % nn == 0 && c.len() == a.len() / self.n);
+        let count = a.len() / nn;
+        let rc = unsafe { sys::idahip_set_linear_dense(self.raw, first as c_int, count as c_int, a.as_ptr(), b.as_ptr(), c.as_ptr()) };
+        self.check(rc).map(|_| ())
+    }
+
+    pub fn set_problem_params(&mut self, first: usize, params: &[f64], nparam: usize) -> Result<(), Error> {
+        assert!(nparam > 0 && params.len() % nparam == 0);
+        let rc = unsafe {
+            sys::idahip_set_problem_params(self.raw, first as c_int, (params.len() / nparam) as c_int, params.as_ptr(), nparam as c_int)
+        };
+        self.check(rc).map(|_| ())
+    }
+
+    /// The user problem of a [`Problem::HostCallback`] context.
+    pub fn set_host_problem(&mut self, problem: Box<dyn HostProblem>) -> Result<(), Error> {
+        let cb = Box::new(CallbackBox { n: self.n, problem });
+        let user = &*cb as *const CallbackBox as *mut c_void;
+        let rc = unsafe { sys::idahip_set_host_problem(self.raw, Some(res_trampoline), Some(jac_trampoline), user) };
+        self.check(rc)?;
+        self.callbacks = Some(cb); // keeps the callbacks alive as long as the ctx
+        Ok(())
+    }
+
+    /// 4 = exact (default, bit-identical to dense_get_rf), 5 = FMA-contracted `fast` LU, 3 = exact cross-check pipeline.
+    pub fn set_lu_variant(&mut self, variant: i32) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_set_lu_variant(self.raw, variant) };
+        self.check(rc).map(|_| ())
+    }
+}
+
+impl Drop for Ctx {
+    fn drop(&mut self) {
+        unsafe {
+            sys::idahip_destroy(self.raw);
+        }
+    }
+}
+
+/// `linear::LSolver` on the device: the reference's `Dense<D>` (crates/linear/src/dense.rs:15-64) with the factorisation and
+/// the substitutions run by libidahip. The matrix crosses PCIe on `setup` (factors come back in place, as the trait's
+/// `&mut mat_a` demands) and on `solve`; inside an ensemble integration nothing does -- use [`HipEnsemble`] for that.
+pub struct HipDense<D: DimName> {
+    ctx: Ctx,
+    d_a: *mut c_double,
+    d_piv: *mut i64,
+    d_x: *mut c_double,
+    d_b: *mut c_double,
+    pivots: Vec<i64>,
+    _dim: PhantomData<D>,
+}
+
+impl<D: DimName> HipDense<D> {
+    fn bytes(count: usize) -> usize {
+        count * std::mem::size_of::<f64>()
+    }
+}
+
+impl<D> LSolver<f64, D> for HipDense<D>
+where
+    D: DimName,
+    DefaultAllocator: Allocator<f64, D> + Allocator<usize, D>,
+{
+    fn new() -> Self {
+        let n = D::dim();
+        let mut ctx = Ctx::new(0, n, 1, Problem::HostCallback).expect("no MI355X visible");
+        let raw = ctx.as_raw();
+        let (d_a, d_piv, d_x, d_b) = unsafe {
+            (
+                sys::idahip_dev_alloc(raw, Self::bytes(n * n)) as *mut c_double,
+                sys::idahip_dev_alloc(raw, Self::bytes(n)) as *mut i64,
+                sys::idahip_dev_alloc(raw, Self::bytes(n)) as *mut c_double,
+                sys::idahip_dev_alloc(raw, Self::bytes(n)) as *mut c_double,
+            )
+        };
+        assert!(!d_a.is_null() && !d_piv.is_null() && !d_x.is_null() && !d_b.is_null(), "device allocation failed");
+        HipDense { ctx, d_a, d_piv, d_x, d_b, pivots: vec![0; n], _dim: PhantomData }
+    }
+
+    fn get_type(&self) -> LSolverType {
+        LSolverType::Direct
+    }
+
+    fn setup<S>(&mut self, mat_a: &mut Matrix<f64, D, D, S>) -> Result<(), linear::Error>
+    where
+        S: StorageMut<f64, D, D>,
+    {
+        let n = D::dim();
+        let raw = self.ctx.as_raw();
+        // nalgebra stores column-major, which is the device layout of one system (include/ida_hip.h)
+        let mut host: Vec<f64> = mat_a.iter().copied().collect();
+        let idx = [0i32];
+        let mut info = [0i32];
+        unsafe {
+            sys::idahip_memcpy_h2d(raw, self.d_a as *mut c_void, host.as_ptr() as *const c_void, Self::bytes(n * n));
+            let rc = sys::idahip_ls_setup(raw, self.d_a, self.d_piv, info.as_mut_ptr(), idx.as_ptr(), 1);
+            assert!(rc >= 0, "{}", self.ctx.last_error());
+            if info[0] != 0 {
+                return Err(linear::Error::LUFactFail { col: info[0] as usize }); // 1-based (dense.rs:121)
+            }
+            sys::idahip_memcpy_d2h(raw, host.as_mut_ptr() as *mut c_void, self.d_a as *const c_void, Self::bytes(n * n));
+            sys::idahip_memcpy_d2h(raw, self.pivots.as_mut_ptr() as *mut c_void, self.d_piv as *const c_void, Self::bytes(n));
+        }
+        for (dst, src) in mat_a.iter_mut().zip(host.iter()) {
+            *dst = *src;
+        }
+        Ok(())
+    }
+
+    fn solve<SA, SB, SC>(
+        &self,
+        mat_a: &Matrix<f64, D, D, SA>,
+        x: &mut Matrix<f64, D, U1, SB>,
+        b: &Matrix<f64, D, U1, SC>,
+        _tol: f64,
+    ) -> Result<(), linear::Error>
+    where
+        SA: StorageMut<f64, D, D>,
+        SB: StorageMut<f64, D>,
+        SC: StorageMut<f64, D>,
+    {
+        let n = D::dim();
+        let raw = self.ctx.raw;
+        let lu: Vec<f64> = mat_a.iter().copied().collect();
+        let rhs: Vec<f64> = b.iter().copied().collect();
+        let mut out = vec![0.0f64; n];
+        let idx = [0i32];
+        unsafe {
+            // the trait hands the factors back in on every call: they are uploaded again, like Dense::solve reads mat_a
+            sys::idahip_memcpy_h2d(raw, self.d_a as *mut c_void, lu.as_ptr() as *const c_void, Self::bytes(n * n));
+            sys::idahip_memcpy_h2d(raw, self.d_piv as *mut c_void, self.pivots.as_ptr() as *const c_void, Self::bytes(n));
+            sys::idahip_memcpy_h2d(raw, self.d_b as *mut c_void, rhs.as_ptr() as *const c_void, Self::bytes(n));
+            let rc = sys::idahip_ls_solve(raw, self.d_a, self.d_piv, self.d_x, self.d_b, 0.0, idx.as_ptr(), 1);
+            assert!(rc >= 0, "{}", self.ctx.last_error());
+            sys::idahip_memcpy_d2h(raw, out.as_mut_ptr() as *mut c_void, self.d_x as *const c_void, Self::bytes(n));
+        }
+        for (dst, src) in x.iter_mut().zip(out.iter()) {
+            *dst = *src;
+        }
+        Ok(())
+    }
+}
+
+impl<D: DimName> Drop for HipDense<D> {
+    fn drop(&mut self) {
+        let raw = self.ctx.raw;
+        unsafe {
+            sys::idahip_dev_free(raw, self.d_a as *mut c_void);
+            sys::idahip_dev_free(raw, self.d_piv as *mut c_void);
+            sys::idahip_dev_free(raw, self.d_x as *mut c_void);
+            sys::idahip_dev_free(raw, self.d_b as *mut c_void);
+        }
+    }
+}
+
+/// Status of one system after a `solve` call (`IdaSolveStatus`, src/lib.rs:58-64, and the `IdaError` codes).
+pub type Status = i32;
+
+/// Counters of `Ida` (src/ida_io.rs:11-117) that `HipEnsemble::counter` returns per system.
+#[derive(Clone, Copy, Debug)]
+pub enum Counter {
+    NumSteps,
+    NumResEvals,
+    NumJacEvals,
+    NumLinSolvSetups,
+    NumNonlinSolvIters,
+    NumErrTestFails,
+    NumNonlinSolvConvFails,
+    LastOrder,
+}
+
+impl Counter {
+    fn code(self) -> c_int {
+        match self {
+            Counter::NumSteps => sys::IDAENS_C_NST,
+            Counter::NumResEvals => sys::IDAENS_C_NRE,
+            Counter::NumJacEvals => sys::IDAENS_C_NJE,
+            Counter::NumLinSolvSetups => sys::IDAENS_C_NSETUPS,
+            Counter::NumNonlinSolvIters => sys::IDAENS_C_NNI,
+            Counter::NumErrTestFails => sys::IDAENS_C_NETF,
+            Counter::NumNonlinSolvConvFails => sys::IDAENS_C_NCFN,
+            Counter::LastOrder => sys::IDAENS_C_KUSED,
+        }
+    }
+}
+
+/// `Ida` for a whole batch: `Ida::new` + `Ida::solve` + getters for every system of a [`Ctx`] (include/ida_ensemble.h).
+pub struct HipEnsemble {
+    raw: *mut sys::idaens,
+    ctx: Ctx,
+}
+
+unsafe impl Send for HipEnsemble {}
+
+impl HipEnsemble {
+    /// `Ida::new(problem, yy0, yp0, ...)` for every system; `yy0`, `yp0` are `[batch][n]`.
+    pub fn new(mut ctx: Ctx, yy0: &[f64], yp0: &[f64]) -> Result<Self, Error> {
+        assert_eq!(yy0.len(), ctx.n * ctx.batch);
+        assert_eq!(yp0.len(), ctx.n * ctx.batch);
+        let mut raw: *mut sys::idaens = ptr::null_mut();
+        let rc = unsafe { sys::idaens_create(&mut raw, ctx.as_raw(), yy0.as_ptr(), yp0.as_ptr()) };
+        if rc != 0 || raw.is_null() {
+            return Err(Error::Library { code: rc, message: ctx.last_error() });
+        }
+        Ok(HipEnsemble { raw, ctx })
+    }
+
+    fn last_error(&self) -> String {
+        unsafe {
+            let p = sys::idaens_last_error(self.raw);
+            if p.is_null() {
+                String::new()
+            } else {
+                CStr::from_ptr(p).to_string_lossy().into_owned()
+            }
+        }
+    }
+
+    /// `Ida::solve(tout, &mut tret, IdaTask::Normal)` for every system: (status, tret) per system.
+    pub fn solve(&mut self, tout: f64) -> Result<(Vec<Status>, Vec<f64>), Error> {
+        let b = self.ctx.batch;
+        let mut tret = vec![0.0f64; b];
+        let mut status = vec![0i32; b];
+        let rc = unsafe { sys::idaens_solve(self.raw, tout, sys::IDAENS_NORMAL, tret.as_mut_ptr(), status.as_mut_ptr(), 0) };
+        if rc < 0 {
+            return Err(Error::Library { code: rc, message: self.last_error() });
+        }
+        Ok((status, tret))
+    }
+
+    /// Root functions g_i = y[comps[i]] - thresholds[i] (the family of examples/roberts.rs), before the first `solve`.
+    pub fn set_roots(&mut self, comps: &[i32], thresholds: &[f64]) -> Result<(), Error> {
+        assert_eq!(comps.len(), thresholds.len());
+        let rc = unsafe { sys::idaens_set_roots(self.raw, comps.len() as c_int, comps.as_ptr(), thresholds.as_ptr()) };
+        if rc != 0 {
+            return Err(Error::Library { code: rc, message: self.last_error() });
+        }
+        Ok(())
+    }
+
+    /// `Ida::get_yy` of every system, `[batch][n]`.
+    pub fn yy(&mut self) -> Vec<f64> {
+        let mut out = vec![0.0f64; self.ctx.n * self.ctx.batch];
+        unsafe {
+            sys::idaens_get_yy(self.raw, out.as_mut_ptr());
+        }
+        out
+    }
+
+    /// `Ida::get_yp` of every system, `[batch][n]`.
+    pub fn yp(&mut self) -> Vec<f64> {
+        let mut out = vec![0.0f64; self.ctx.n * self.ctx.batch];
+        unsafe {
+            sys::idaens_get_yp(self.raw, out.as_mut_ptr());
+        }
+        out
+    }
+
+    /// `Ida::get_dky(t, k, ..)` of every system: (status, `[batch][n]`).
+    pub fn get_dky(&mut self, t: f64, k: usize) -> Result<(Vec<Status>, Vec<f64>), Error> {
+        let mut out = vec![f64::NAN; self.ctx.n * self.ctx.batch];
+        let mut status = vec![0i32; self.ctx.batch];
+        let rc = unsafe { sys::idaens_get_dky(self.raw, t, k as c_int, out.as_mut_ptr(), status.as_mut_ptr()) };
+        if rc < 0 {
+            return Err(Error::Library { code: rc, message: self.last_error() });
+        }
+        Ok((status, out))
+    }
+
+    pub fn counter(&self, which: Counter) -> Vec<i64> {
+        let mut out = vec![0i64; self.ctx.batch];
+        unsafe {
+            sys::idaens_get_counter(self.raw, which.code(), out.as_mut_ptr());
+        }
+        out
+    }
+
+    pub fn ctx(&mut self) -> &mut Ctx {
+        &mut self.ctx
+    }
+}
+
+impl Drop for HipEnsemble {
+    fn drop(&mut self) {
+        unsafe {
+            sys::idaens_destroy(self.raw); // before the ctx it points into (field order: `ctx` drops after this body)
+        }
+    }
+}
