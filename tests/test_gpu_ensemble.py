@@ -392,8 +392,9 @@ def test_get_dky_matches_the_oracle(kind):
             assert o.solve(t)[0] == 0
         assert o.get("tn") == tn[s] and int(o.get("kused")) == kused[s]
         oracles.append(o)
-    t = touts[-1] - 0.37 * hused.min()  # inside the last step of every system (all have stepped past touts[-1])
-    for k in range(0, int(kused.max()) + 2):
+    # touts[-1] lies inside the last step of every system (all have stepped past it); a little earlier it still does for
+    # most and is IDA_BAD_T for the others -- both outcomes must equal the oracle's
+    for t, k in [(tt, kk) for tt in (touts[-1], touts[-1] - 0.37 * hused.min()) for kk in range(0, int(kused.max()) + 2)]:
         status, dky = ens.get_dky(t, k)
         for s in range(B):
             st_o, d_o = oracles[s].get_dky(t, k)
@@ -401,7 +402,7 @@ def test_get_dky_matches_the_oracle(kind):
             if st_o == 0:
                 assert np.array_equal(dky[s], d_o), (k, s)
             else:
-                assert st_o == -25 and k > kused[s] and np.isnan(dky[s]).all()
+                assert st_o in (-25, -26) and (st_o == -26 or k > kused[s]) and np.isnan(dky[s]).all()
     status, _ = ens.get_dky(float(tn.min() - 3.0 * hused.max()), 0)   # before the last step of every system
     assert (status == -26).all()
     ens.close()
