@@ -49,7 +49,11 @@ const char* idaens_last_error(const idaens* e);
 
 /* optional inputs (the reference has defaults only, src/lib.rs:309-321; setters follow C IDA's names) */
 int idaens_set_max_num_steps(idaens* e, long mxstep); /* 0 = unlimited; default 500 (MXSTEP_DEFAULT) */
-int idaens_set_max_ord(idaens* e, int maxord);        /* 1..5, default 5 */
+int idaens_set_max_ord(idaens* e, int maxord);
+/* on (default; always off for IDAHIP_HOST_CALLBACK problems): a Newton solve runs its first two iterations and their
+ * convergence tests in one device call (idahip_newton_iter2) instead of one host round trip per iteration. Results are
+ * identical either way; the switch exists for measurements. */
+int idaens_set_fused_newton(idaens* e, int on);        /* 1..5, default 5 */
 /* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
  * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call
  * before the first solve; idaens_solve then reports IDAENS_ROOT_RETURN with tret = the root, yy/yp = the solution there,

@@ -72,6 +72,7 @@ const char* idahip_last_error(const idahip_ctx* ctx);
 int idahip_sync(idahip_ctx* ctx);
 int idahip_n(const idahip_ctx* ctx);
 int idahip_batch(const idahip_ctx* ctx);
+int idahip_kind(const idahip_ctx* ctx); /* the idahip_problem the ctx was created with */
 
 /* TolControlSS (natol == 1) / TolControlSV (natol == n), src/tol_control.rs:6-82; shared by the ensemble */
 int idahip_set_tolerances(idahip_ctx* ctx, double rtol, const double* hAtol, int natol);
@@ -123,6 +124,17 @@ int idahip_nls_sys_setup(idahip_ctx* ctx, const double* hTn, const double* hCj, 
 int idahip_nls_sys(idahip_ctx* ctx, const double* hTn, const double* hCj, int reset_ee, const int32_t* hIdx, int nsys);
 int idahip_nls_lsetup(idahip_ctx* ctx, const double* hTn, const double* hCj, int32_t* hInfo, const int32_t* hIdx, int nsys);
 int idahip_newton_iter(idahip_ctx* ctx, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys);
+/* The first two iterations of Newton::solve in one call, without the host in between (first slice):
+ *   newton body (m = 0) -> idaNlsConvTest -> NLProblem::sys -> newton body (m = 1) -> idaNlsConvTest
+ * for the listed systems, each of which must be at curiter = 0 with its residual in `delta` (i.e. right after idahip_nls_sys
+ * or idahip_nls_sys_setup). The two tests need no powf (m = 0: two comparisons; m = 1: rate = delnrm / oldnrm exactly,
+ * src/ida_nls.rs:243-262), so they are decided on the device with the caller's per-system hToldel, hSs, hEpsNewt; a system
+ * that has ended is skipped by the kernels that follow. Out: hDelnrm[s][0..2) = the norms of the two corrections (the second
+ * is 0 if not run), hConv[s] = 0 go on with m = 2 (NLProblem::sys first) | 1 converged at m = 0 | 2 converged at m = 1 |
+ * 3 ConvergenceRecover at m = 1. The caller updates oldnrm = hDelnrm[s][0] and, if the second iteration ran and did not end
+ * in 3, ss = rate / (1 - rate) with rate = hDelnrm[s][1] / hDelnrm[s][0]. Not for IDAHIP_HOST_CALLBACK. */
+int idahip_newton_iter2(idahip_ctx* ctx, const double* hScale, const double* hTn, const double* hCj, const double* hToldel,
+                        const double* hSs, const double* hEpsNewt, double* hDelnrm, int32_t* hConv, const int32_t* hIdx, int nsys);
 
 /* ---- vector parts of the stepper that touch the same device-resident state ----
  * init_first : initial_setup + first-call block of Ida::solve (src/lib.rs:537-545, src/impl_solve.rs:120-126):

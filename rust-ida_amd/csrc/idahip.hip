@@ -595,13 +595,13 @@ int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, con
         KTimer kt(c, IDAHIP_K_NEWTON_ITER, nsys);
         if (n <= TINY_N) {
             hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
-                               (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out);
+                               (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, (const int*)nullptr);
         } else if (n % 2 == 0) {
             hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out);
+                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, (const int*)nullptr);
         } else {
             hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out);
+                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, (const int*)nullptr);
         }
         if ((rc = post_launch(c, "newton_iter"))) return rc;
     }
@@ -610,6 +610,77 @@ int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, con
     for (int s = 0; s < nsys; ++s) hDelnrm[s] = sqrt(h[s] / (double)n);
     return 0;
 }
+
+// One Newton iteration body for the listed systems (shared by idahip_newton_iter and idahip_newton_iter2)
+static int launch_newton_iter(idahip_ctx* c, const int* d_idx, const double* d_scale, double* d_out, const int* d_skip, int nsys) {
+    const int n = c->n;
+    if (n <= TINY_N) {
+        hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
+                           (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, d_skip);
+    } else if (n % 2 == 0) {
+        hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+    } else {
+        hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+    }
+    return post_launch(c, "newton_iter");
+}
+
+int idahip_newton_iter2(idahip_ctx* c, const double* hScale, const double* hTn, const double* hCj, const double* hToldel, const double* hSs,
+                        const double* hEpsNewt, double* hDelnrm, int32_t* hConv, const int32_t* hIdx, int nsys) {
+    DevGuard dev_guard__(c);
+    int rc = check_list(c, hIdx, nsys);
+    if (rc) return rc;
+    if (!hScale || !hTn || !hCj || !hToldel || !hSs || !hEpsNewt || !hDelnrm || !hConv) return fail(c, -2, "null argument");
+    if (c->kind == IDAHIP_HOST_CALLBACK) return fail(c, -2, "idahip_newton_iter2 needs a device residual (not for IDAHIP_HOST_CALLBACK)");
+    if (nsys == 0) return 0;
+    const int n = c->n;
+    ArgPack ap;
+    if ((rc = ap.begin(c))) return rc;
+    SysArgs a;
+    a.idx = ap.in(hIdx, nsys);
+    a.tn = ap.in(hTn, nsys);
+    a.cj = ap.in(hCj, nsys);
+    const double* d_scale = ap.in(hScale, nsys);
+    const double* d_toldel = ap.in(hToldel, nsys);
+    const double* d_ss = ap.in(hSs, nsys);
+    const double* d_eps = ap.in(hEpsNewt, nsys);
+    double* d_dn = ap.out<double>(2 * (size_t)nsys);
+    int* d_conv = ap.out<int>(nsys);
+    double* d_sum = ap.out<double>(nsys);
+    if ((rc = ap.ok())) return rc;
+    if ((rc = ap.upload())) return rc;
+    fill_sys_args(c, a, 0);
+    const dim3 tg((nsys + 255) / 256), tb(256);
+    {   // iteration m = 0 and its convergence test
+        KTimer kt(c, IDAHIP_K_NEWTON_ITER, nsys);
+        if ((rc = launch_newton_iter(c, a.idx, d_scale, d_sum, nullptr, nsys))) return rc;
+        hipLaunchKernelGGL(ctest_kernel, tg, tb, 0, c->stream, (const double*)d_sum, n, 0, d_toldel, d_ss, d_eps, d_dn, d_conv, nsys);
+    }
+    a.skip = d_conv;
+    {   // NLProblem::sys at the corrected y for the systems that go on (conv == 0)
+        KTimer kt(c, IDAHIP_K_SYS, 0);
+        if ((rc = launch_sys(c, a, nsys, nullptr, hTn, hIdx))) return rc;
+    }
+    {   // iteration m = 1 and its convergence test
+        KTimer kt(c, IDAHIP_K_NEWTON_ITER, 0);
+        if ((rc = launch_newton_iter(c, a.idx, d_scale, d_sum, d_conv, nsys))) return rc;
+        hipLaunchKernelGGL(ctest_kernel, tg, tb, 0, c->stream, (const double*)d_sum, n, 1, d_toldel, d_ss, d_eps, d_dn, d_conv, nsys);
+        if ((rc = post_launch(c, "ctest"))) return rc;
+    }
+    if ((rc = ap.fetch())) return rc;
+    const double* hd = ap.host_of((const double*)d_dn);
+    const int* hc = ap.host_of((const int*)d_conv);
+    for (int s = 0; s < nsys; ++s) {
+        hDelnrm[2 * s] = hd[2 * s];
+        hDelnrm[2 * s + 1] = hd[2 * s + 1];
+        hConv[s] = hc[s];
+    }
+    return 0;
+}
+
+int idahip_kind(const idahip_ctx* c) { return c ? (int)c->kind : -1; }
 
 // ------------------------------------------------------------------------------------------------ stepper vector ops
 int idahip_init_first(idahip_ctx* c, double* hYpnorm, double* hPhi0Nrm, const int32_t* hIdx, int nsys) {

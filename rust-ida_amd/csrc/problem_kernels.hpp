@@ -27,6 +27,7 @@ struct SysArgs {
     const double* cj;  // [nsys]
     int n;
     int reset_ee;
+    const int* skip = nullptr;  // optional, per list position: nonzero = leave this system alone (idahip_newton_iter2)
 };
 
 // ------------------------------------------------------------------------------------------------ tiny problems
@@ -58,6 +59,7 @@ template <int KIND>
 __global__ void tiny_sys_kernel(SysArgs a, const double* __restrict__ params, int nparam, int nsys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
+    if (a.skip && a.skip[s] != 0) return;
     const int b = a.idx[s];
     const long vb = (long)b * 3;
     const double cj = a.cj[s];
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
     const int n = a.n;
     double* syy = sm;
     double* syp = sm + n;
+    if (a.skip && a.skip[blockIdx.x] != 0) return;
     const int b = a.idx[blockIdx.x];
     const long vb = (long)b * n;
     const double cj = a.cj[blockIdx.x];
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* 
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
     double* syy = sm;
+    if (a.skip && a.skip[blockIdx.x] != 0) return;
     const int b = a.idx[blockIdx.x];
     const long vb = (long)b * n;
     const double cj = a.cj[blockIdx.x];
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats
 // packs them for the listed systems, the host evaluates F, `post` scatters the residuals into delta and savres.
 __global__ __launch_bounds__(256) void callback_pre_kernel(SysArgs a, double* __restrict__ stage) {
     const int n = a.n;
+    if (a.skip && a.skip[blockIdx.x] != 0) return;
     const int b = a.idx[blockIdx.x];
     const long vb = (long)b * n;
     const double cj = a.cj[blockIdx.x];
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void callback_pre_kernel(SysArgs a, double* __
 }
 __global__ __launch_bounds__(256) void callback_post_kernel(SysArgs a, const double* __restrict__ stage) {
     const int n = a.n;
+    if (a.skip && a.skip[blockIdx.x] != 0) return;
     const int b = a.idx[blockIdx.x];
     const long vb = (long)b * n;
     const double* __restrict__ r = stage + (long)blockIdx.x * 3 * n + 2 * n;

@@ -228,10 +228,11 @@ template <int VEC>
 __global__ __launch_bounds__(256, 4) void newton_iter_kernel(const double* __restrict__ LU, const int* __restrict__ perm, double* __restrict__ delta,
                                                           double* __restrict__ ee, const double* __restrict__ ewt, int n,
                                                           const int* __restrict__ idx, const double* __restrict__ scale,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, const int* __restrict__ skip) {
     extern __shared__ __align__(16) double sm[];
     double* bs = sm;
     double* sq = sm + n;
+    if (skip && skip[blockIdx.x] != 0) return;  // (idahip_newton_iter2: this system's Newton solve has ended)
     const int b = idx[blockIdx.x];
     const int t = threadIdx.x;
     const long vb = (long)b * n;
@@ -296,9 +297,10 @@ __global__ void tiny_wrms_kernel(const double* X, const double* W, double* out, 
 }
 
 __global__ void tiny_newton_iter_kernel(const double* LU, const long long* piv, double* delta, double* ee, const double* ewt, int n,
-                                        const int* idx, int nsys, const double* scale, double* out) {
+                                        const int* idx, int nsys, const double* scale, double* out, const int* skip) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
+    if (skip && skip[s] != 0) return;
     const int b = idx[s];
     const long vb = (long)b * n;
     double v[TINY_N];
@@ -314,6 +316,41 @@ __global__ void tiny_newton_iter_kernel(const double* LU, const long long* piv, 
         acc = acc + p * p;
     }
     out[s] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ idaNlsConvTest on the device
+// The first two convergence tests of a Newton solve (src/ida_nls.rs:243-262) need no pow: m = 0 is two comparisons, m = 1 has
+// rate = (delnrm / oldnrm)^(1/1) = delnrm / oldnrm exactly. sum[q] is the kernel's sequential sum of (delta_i ewt_i)^2;
+// delnrm = sqrt(sum / n) -- a correctly rounded division and square root, as on the host (norm_rms.rs:36-37).
+// conv[q]: 0 = keep iterating, 1 = converged at m = 0, 2 = converged at m = 1, 3 = ConvergenceRecover at m = 1 (rate > 0.9).
+__global__ void ctest_kernel(const double* __restrict__ sum, int n, int m, const double* __restrict__ toldel, const double* __restrict__ ss,
+                             const double* __restrict__ eps_newt, double* __restrict__ delnrm /*[nsys][2]*/, int* __restrict__ conv,
+                             int nsys) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nsys) return;
+    if (m == 0) {
+        const double d0 = sqrt(sum[q] / (double)n);
+        delnrm[2 * q] = d0;
+        delnrm[2 * q + 1] = 0.0;
+        int c = 0;
+        if (d0 <= 0.0001 * toldel[q]) c = 1;       // ida_nls.rs:245
+        else if (ss[q] * d0 <= eps_newt[q]) c = 1;  // ida_nls.rs:260 with the ss of the previous solve / setup
+        conv[q] = c;
+    } else {
+        if (conv[q] != 0) return;
+        const double d0 = delnrm[2 * q];
+        const double d1 = sqrt(sum[q] / (double)n);
+        delnrm[2 * q + 1] = d1;
+        const double rate = d1 / d0;               // powf(base, 1/m) with m = 1 (ida_nls.rs:249-253)
+        int c = 0;
+        if (rate > 0.9) {                          // RATEMAX (ida_nls.rs:15,254)
+            c = 3;
+        } else {
+            const double ss1 = rate / (1.0 - rate);
+            if (ss1 * d1 <= eps_newt[q]) c = 2;
+        }
+        conv[q] = c;
+    }
 }
 
 }  // namespace idahip

@@ -107,6 +107,7 @@ struct idaens {
     double t0 = 0.0;                // every system starts at tn = t0 (Sys default)
     int64_t retired_iters = 0, passes = 0;  // idaens_stream: Newton iterations / integrations of systems already restarted
     bool have_ic = false, streaming = false;
+    bool fused_newton = true;  // first two Newton iterations and their convergence tests in one device call (idahip_newton_iter2)
     std::vector<int64_t> start_round;  // idaens_stream with a stagger: the round at which each system first enters
     // root functions g_i(t, y, y') = y[rt_comp[i]] - rt_thr[i] (the form of the reference's Roberts example,
     // src/sample_problems/roberts.rs: g0 = y0 - 1e-4, g1 = y2 - 0.01); nrtfn == 0: no root finding
@@ -679,9 +680,72 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
         if (I.empty()) break;
         sc.clear();
         for (int b : I) sc.push_back(S[b].cjratio != 1.0 ? 2.0 / (1.0 + S[b].cjratio) : 1.0);  // ida_ls.rs:406-410
+        C.clear();
+        // what follows a convergence test (newton.rs:109-153): converged / iterate again / ConvergenceRecover
+        auto after_ctest = [&](int b, int ret, bool converged) {
+            Sys& s = S[b];
+            if (ret == NLS_SUCCESS && converged) {
+                s.jcur = false;
+                s.nls_ret = NLS_SUCCESS;
+                return;
+            }
+            if (ret == NLS_SUCCESS) {
+                s.curiter += 1;
+                if (s.curiter >= MAXNLSIT) ret = NLS_CONV_RECVR;
+            }
+            if (ret == NLS_SUCCESS) {
+                C.push_back(b);  // sys(y) then iterate again
+                return;
+            }
+            // ConvergenceRecover
+            if (!s.jcur) {
+                s.nconvfails += 1;
+                s.call_lsetup = true;
+                jbad[b] = 1;
+                R.push_back(b);
+            } else {
+                s.nconvfails += 1;
+                s.nls_ret = NLS_CONV_RECVR;
+            }
+        };
+        bool all_fresh = e->fused_newton;
+        for (int b : I) all_fresh = all_fresh && S[b].curiter == 0;
+        if (all_fresh) {
+            // the first two iterations in one device call: both convergence tests are decided there (no powf needed for
+            // m <= 1, ida_nls.rs:243-262); the scalar state is brought up to date here from the two norms it returns
+            tn.clear(); cj.clear();
+            std::vector<double> told, ssv, epsv;
+            for (int b : I) {
+                tn.push_back(S[b].tn); cj.push_back(S[b].cj);
+                told.push_back(S[b].toldel); ssv.push_back(S[b].ss); epsv.push_back(S[b].eps_newt);
+            }
+            nrm.assign(2 * I.size(), 0.0);
+            std::vector<int32_t> conv(I.size(), 0);
+            ENS_CALL(e, idahip_newton_iter2(e->ctx, sc.data(), tn.data(), cj.data(), told.data(), ssv.data(), epsv.data(), nrm.data(),
+                                            conv.data(), I.data(), (int)I.size()));
+            for (size_t q = 0; q < I.size(); ++q) {
+                const int b = I[q];
+                Sys& s = S[b];
+                s.niters += 1;
+                s.oldnrm = nrm[2 * q];           // m = 0 (ida_nls.rs:244)
+                if (conv[q] == 1) {
+                    after_ctest(b, NLS_SUCCESS, true);
+                    continue;
+                }
+                s.curiter = 1;                   // the device went on: sys(y), second iteration, test with m = 1
+                s.nre += 1;
+                s.niters += 1;
+                const double rate = nrm[2 * q + 1] / s.oldnrm;  // powf(base, 1/1)
+                if (conv[q] == 3) {
+                    after_ctest(b, NLS_CONV_RECVR, false);
+                    continue;
+                }
+                s.ss = rate / (1.0 - rate);
+                after_ctest(b, NLS_SUCCESS, conv[q] == 2);
+            }
+        } else {
         nrm.assign(I.size(), 0.0);
         ENS_CALL(e, idahip_newton_iter(e->ctx, sc.data(), nrm.data(), I.data(), (int)I.size()));
-        C.clear();
         for (size_t q = 0; q < I.size(); ++q) {
             const int b = I[q];
             Sys& s = S[b];
@@ -702,29 +766,8 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
                 else s.ss = rate / (1.0 - rate);
             }
             if (ret == NLS_SUCCESS && !converged && s.ss * delnrm <= s.eps_newt) converged = true;
-            if (ret == NLS_SUCCESS && converged) {
-                s.jcur = false;
-                s.nls_ret = NLS_SUCCESS;
-                continue;
-            }
-            if (ret == NLS_SUCCESS) {
-                s.curiter += 1;
-                if (s.curiter >= MAXNLSIT) ret = NLS_CONV_RECVR;
-            }
-            if (ret == NLS_SUCCESS) {
-                C.push_back(b);  // sys(y) then iterate again
-                continue;
-            }
-            // ConvergenceRecover
-            if (!s.jcur) {
-                s.nconvfails += 1;
-                s.call_lsetup = true;
-                jbad[b] = 1;
-                R.push_back(b);
-            } else {
-                s.nconvfails += 1;
-                s.nls_ret = NLS_CONV_RECVR;
-            }
+            after_ctest(b, ret, converged);
+        }
         }
         if (!C.empty()) {
             tn.clear(); cj.clear();
@@ -948,6 +991,7 @@ int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const doubl
     e->ctx = ctx;
     e->n = idahip_n(ctx);
     e->batch = idahip_batch(ctx);
+    e->fused_newton = idahip_kind(ctx) != IDAHIP_HOST_CALLBACK;  // a host residual cannot run between two device iterations
     e->sys.resize(e->batch);
     // Ida::new (lib.rs:291-293): phi[0] = yy0, phi[1] = yp0; yy/yp start as yy0/yp0 (ida_nls.rs:83-84)
     int rc = idahip_upload(ctx, IDAHIP_F_PHI0, 0, e->batch, hYY0);
@@ -975,6 +1019,12 @@ int idaens_set_max_num_steps(idaens* e, long mxstep) {
     e->mxstep = mxstep;
     return 0;
 }
+int idaens_set_fused_newton(idaens* e, int on) {
+    if (!e) return -1;
+    e->fused_newton = on != 0 && idahip_kind(e->ctx) != IDAHIP_HOST_CALLBACK;
+    return 0;
+}
+
 int idaens_set_max_ord(idaens* e, int maxord) {
     if (!e || maxord < 1 || maxord > MAXORD_DEFAULT) return -1;
     e->maxord = maxord;

@@ -29,16 +29,16 @@ K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac", "lu_
 
 # symbols declared in include/ida_hip.h / include/ida_ensemble.h (checked by tests/test_abi_symbols.py)
 HIP_SYMBOLS = [
-    "idahip_create", "idahip_destroy", "idahip_last_error", "idahip_sync", "idahip_n", "idahip_batch", "idahip_set_tolerances",
+    "idahip_create", "idahip_destroy", "idahip_last_error", "idahip_sync", "idahip_n", "idahip_batch", "idahip_kind", "idahip_set_tolerances",
     "idahip_set_problem_params", "idahip_set_linear_dense", "idahip_set_host_problem", "idahip_upload", "idahip_download", "idahip_download_lu",
     "idahip_dev_alloc", "idahip_dev_free", "idahip_memcpy_h2d", "idahip_memcpy_d2h", "idahip_ls_setup", "idahip_ls_solve",
-    "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_init_first", "idahip_scale_phi1",
+    "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_newton_iter2", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [
-    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_roots",
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_roots",
     "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
@@ -413,6 +413,9 @@ class Ensemble:
         if out.size:
             self.E.idaens_get_roots(self.h, _p(out, i32p))
         return out
+
+    def set_fused_newton(self, on):
+        self.E.idaens_set_fused_newton(self.h, int(on))
 
     def set_max_ord(self, maxord):
         if self.E.idaens_set_max_ord(self.h, int(maxord)) != 0:

@@ -452,3 +452,31 @@ def test_user_problem_through_host_callbacks_reproduces_the_roberts_example():
     y_end = ens.yy()[0]
     assert [float.hex(float(v)) for v in y_end] == ["0x1.a1d277a766cb0p-25", "0x1.b61e4814ea4bbp-43", "0x1.fffffe5e2d1adp-1"]
     ens.close()
+
+
+@pytest.mark.parametrize("kind", ["linear_dense", "lorenz63", "heat1d", "roberts"])
+def test_fused_first_two_newton_iterations_change_nothing(kind):
+    """SURVEY 8(f)-2, first slice: with idahip_newton_iter2 the first two Newton iterations of a solve and their convergence
+    tests (ida_nls.rs:243-262, no powf needed for m <= 1) run in one device call. Every parity test of this file runs with
+    it (the default); here the same integration with the switch off -- one host round trip per iteration, ctest on the
+    host -- must give identical bits and counters, and the oracle's."""
+    import idahip
+    from idahip import problems
+    p = {"linear_dense": lambda: problems.linear_dense(n=40, batch=9), "lorenz63": lambda: problems.lorenz63(batch=300),
+         "heat1d": lambda: problems.heat1d(n=40, batch=4), "roberts": problems.roberts}[kind]()
+    touts = p["touts"][:6]
+    out = {}
+    for fused in (1, 0):
+        ens = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+        ens.set_fused_newton(fused)
+        status, tret, reached = ens.solve_schedule(touts)
+        assert (status == 0).all()
+        out[fused] = (ens.yy(), ens.yp(), ens.counters(), ens.real("hused"))
+        ens.close()
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][3], out[0][3])
+    for k in out[1][2]:
+        assert np.array_equal(out[1][2][k], out[0][2][k]), k
+    ref = run_oracle(p, touts=touts)
+    assert np.array_equal(out[1][0], ref["yy"][-1])
+    for k in CNT:
+        assert np.array_equal(out[1][2][k], ref["counters"][k]), k
