@@ -326,6 +326,21 @@ def main():
     tim = run.timed_steps(args.steps, 1)
     tim2 = run.timed_steps(args.steps, 2)
 
+    unfused = None
+    if world == 1 and not args.no_extras:
+        # the same K steps with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
+        # device-side convergence tests (first slice); results are identical, only the pace changes
+        run.ens.set_fused_newton(0)
+        for _ in range(max(2, args.warmup // 2)):
+            run.step()
+        run.sync()
+        it1, t1 = run.total_iters(), time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        run.sync()
+        unfused = (run.total_iters() - it1) / (time.perf_counter() - t1)
+        run.ens.set_fused_newton(1)
+
     extras = None
     if world == 1 and not args.no_extras:
         passes = [run.whole_pass(4) for _ in range(3)]
@@ -422,6 +437,10 @@ def main():
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
         }
+        if unfused is not None:
+            out["newton_fusion"] = {"value_with_host_ctest_every_iteration": unfused, "unit": "Newton iters/s",
+                                    "note": "`value` runs with idahip_newton_iter2 (first two iterations + convergence tests in one "
+                                            "device call); this is the same stream with one host round trip per iteration"}
         if extras:
             out.update(extras)
         if TIME_ALL:
