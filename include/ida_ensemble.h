@@ -64,7 +64,9 @@ int idaens_get_roots(const idaens* e, int32_t* out /* [batch][nroots] */);
 
 /* Ida::solve(tout, &mut tret, itask) for every system (src/impl_solve.rs:69-376). hTret/hStatus: [batch].
  * max_rounds > 0 bounds the number of lock-step attempt rounds (systems still stepping report IDAENS_UNFINISHED and
- * resume on the next call with the same tout). Returns 0, or < 0 on a device/ABI failure. */
+ * resume on the next call with the same tout). Returns 0, or < 0 on a device/ABI failure.
+ * A negative per-system status (an IdaError) is sticky: later solve calls leave that system alone and report the same status
+ * again (the reference's Ida::solve can be called again after an error and would try to continue). */
 int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds);
 
 /* The same for a whole output schedule: for every system Ida::solve(touts[0]), Ida::solve(touts[1]), ... in IDA_NORMAL

@@ -11,7 +11,9 @@
 //   handle_n_flag         /root/reference/src/lib.rs:1120-1244
 //   complete_step         /root/reference/src/impl_complete_step.rs:22-177
 //   get_solution          /root/reference/src/lib.rs:1274-1343      (coefficients; the sums run on the device)
+//   get_dky               /root/reference/src/lib.rs:424-529        (coefficients; quirk Q9: C IDA's loop bound)
 //   stop_test1/2          /root/reference/src/impl_stop_test.rs:36-211 (no tstop: the reference has no setter)
+//   r_check1/2/3, root_finding  /root/reference/src/impl_r_check.rs:32-576 (scalar bracketing here, y(t) interpolated on the device)
 // Vectors live on the device; this file talks to it only through include/ida_hip.h. The oracle is NOT used here.
 //
 // Lock-step execution: one "round" is one step attempt (set_coeffs -> predict -> Newton -> error test -> accept or
@@ -20,8 +22,12 @@
 //
 // Deviations from the reference text, identical to the oracle's: Q1 (jac at tn), Q2 (LU failure is a
 // recoverable lsetup failure), Q3 (Newton breaks out on ConvergenceRecover with a current Jacobian), Q4 (Newton
-// ConvergenceRecover is recoverable at step level), Q5 (reset() rescales phi[1] only). Root finding, constraints
-// and tstop are out of scope.
+// ConvergenceRecover is recoverable at step level), Q5 (reset() rescales phi[1] only). Constraints and tstop are out of
+// scope (the reference has no setter for either).
+//
+// A system whose solve call ended in a fatal IdaError (too much work, error-test or convergence failures, ...) is `dead`:
+// the reference's Ida::solve could be called again after such an error and would try to continue; here the status is
+// sticky -- later calls skip the system and report the same status (include/ida_ensemble.h says so).
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>

@@ -155,12 +155,16 @@ class Ctx:
         self.h = h
 
     def close(self):
+        """idahip_destroy. Refused while an Ensemble created on this ctx is still open: libidaens keeps the raw ctx pointer."""
         if getattr(self, "h", None) is not None and self.h.value:
+            if getattr(self, "_ensembles", 0) > 0:
+                raise IdaHipError("close() of a Ctx with %d open Ensemble(s): close them first" % self._ensembles)
             self.H.idahip_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
         try:
+            self._ensembles = 0  # garbage collection: any Ensemble holds a reference to this object, so none is left
             self.close()
         except Exception:
             pass
@@ -386,11 +390,13 @@ class Ensemble:
         if rc != 0:
             raise IdaHipError("idaens_create failed (%d): %s" % (rc, ctx.H.idahip_last_error(ctx.h).decode()))
         self.h = h
+        ctx._ensembles = getattr(ctx, "_ensembles", 0) + 1
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             self.E.idaens_destroy(self.h)
             self.h = C.c_void_p()
+            self.ctx._ensembles -= 1
 
     def __del__(self):
         try:
