@@ -93,15 +93,10 @@ def profiled_traffic(kernel_prefix):
         s = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
     except Exception:
         return None
-    tot, systems = 0.0, 0
-    for k, v in s.get("kernels", {}).items():
-        if k.startswith(kernel_prefix) and "hbm_read_GB_total" in v:
-            tot += v["hbm_read_GB_total"] + v["hbm_write_GB_total"]
-    systems = s.get("bench", {}).get("lu_kernels_rank0", {}).get("lu_trail", {}).get("matrices", 0) or \
-        s.get("bench", {}).get("kernel_classes_rank0", {}).get("lu", {}).get("systems", 0)
-    if not tot or not systems:
+    tot = sum(v for k, v in s.get("lu_hbm_bytes_per_matrix", {}).items() if k.startswith(kernel_prefix))
+    if not tot:
         return None
-    return {"hbm_bytes_per_matrix": int(tot * 1e9 / systems), "source": PMC_SUMMARY, "commit": s.get("commit")}
+    return {"hbm_bytes_per_matrix": int(tot), "source": PMC_SUMMARY, "commit": s.get("commit")}
 
 
 def lu_plus_solve(tim, n, arithmetic):
@@ -391,7 +386,7 @@ def main():
             mats = tim2["lu"]["systems"]                    # matrices factorised in the level-2 pass
             v = tim2["lu_trail"]
             tfl = flops * mats / (v["ms"] * 1e-3) / 1e12
-            tr = profiled_traffic("void idahip::lu_trail64w_kernel") if (args.workload == "linear_dense" and args.n == 512) else None
+            tr = profiled_traffic("lu_trail64w_kernel") if (args.workload == "linear_dense" and args.n == 512) else None
             roof = {"bound": "valu", "kernel": "lu_trail64w_kernel<1024, false> (rank-64 trailing update + U12 solve of the batched getrf)",
                     "share_of_device_time": round(cand[dom] / total_ms, 4),
                     "achieved": round(tfl, 2), "peak": VALU_UNFUSED_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / VALU_UNFUSED_TFLOPS, 4),

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export IDAHIP_GEN_PROCS=1   # no forked generator processes under the profiler
 export IDAHIP_BENCH_TIME_ALL=1
-ARGS="$ROOT/bench.py --steps 40 --warmup 0 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --steps 40 --warmup 0 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- python3 $ARGS > "$OUT/bench.json" 2> "$OUT/kt.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- python3 $ARGS > "$OUT/fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 $ARGS > "$OUT/write.json" 2> "$OUT/write.err"

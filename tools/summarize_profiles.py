@@ -27,9 +27,18 @@ for name, d in k.items():
         d["hbm_write_GB_total"] = round(w.get(name, 0.0) * 1024 / 1e9, 3)
         d["hbm_bytes_per_launch"] = int((2.0 * f[name] + w.get(name, 0.0)) * 1024 / max(1, fc[name]))
         d["hbm_GBps"] = round((2.0 * f[name] + w.get(name, 0.0)) * 1024 / 1e9 / (d["total_ms"] / 1e3), 1)
-b = json.load(open(bench))
-res = {"bench": {kk: b[kk] for kk in ("value", "steps", "warmup", "ms_per_step", "kernel_classes_rank0")}, "kernels": k,
-       "note": "kernel stats and PMC passes are separate runs of the same command (python3 bench.py --steps 40 --warmup 0 --no-cpu-baseline)"}
+import os
+b = json.loads(open(bench).read().strip().splitlines()[-1])
+lu_mats = b["kernel_classes_rank0"]["lu"]["systems"]
+res = {"commit": os.environ.get("GIT_COMMIT", "unknown"),
+       "bench": {**{kk: b[kk] for kk in ("value", "steps", "warmup", "ms_per_step", "kernel_classes_rank0") if kk in b},
+                 "lu_kernels_rank0": b.get("lu_kernels_rank0"), "lu_matrices": lu_mats},
+       "kernels": k,
+       "lu_hbm_bytes_per_matrix": {name: int((d["hbm_read_GB_total"] + d["hbm_write_GB_total"]) * 1e9 / max(1, lu_mats))
+                                   for name, d in k.items() if name.startswith("lu_") and "hbm_read_GB_total" in d},
+       "note": "kernel stats and PMC passes are separate runs of the same command (python3 bench.py --steps 40 --warmup 0 "
+               "--no-cpu-baseline --no-extras under IDAHIP_BENCH_TIME_ALL=1: the per-kernel LU timers cover every launch of the process)"}
+res["lu_hbm_bytes_per_matrix"]["all LU kernels"] = sum(res["lu_hbm_bytes_per_matrix"].values())
 json.dump(res, open(out, "w"), indent=1)
 for name, d in sorted(k.items(), key=lambda x: -x[1]["total_ms"])[:10]:
     print("%-28s calls %5d total %9.2f ms avg %9.1f us  %s" % (name[:28], d["calls"], d["total_ms"], d["avg_us"],
