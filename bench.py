@@ -320,6 +320,8 @@ def main():
     # ---- untimed repetitions of the same K steps with event timers: per kernel class, then per kernel of the LU
     tim = run.timed_steps(args.steps, 1)
     tim2 = run.timed_steps(args.steps, 2)
+    if TIME_ALL:
+        tim = tim2  # the timers were never reset: both are totals over every launch of the process
 
     unfused = None
     if world == 1 and not args.no_extras:
