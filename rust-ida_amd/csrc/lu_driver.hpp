@@ -50,13 +50,29 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp); the second launch finishes
             // the few systems whose matrices have exact zeros or special values (it returns at once for the others)
+            const int ns = (n - k0 + 63) / 64;
+#define IDAHIP_WP_LAUNCH(F, NSV) \
+    hipLaunchKernelGGL((lu_wavepanel_kernel<F, false, NSV>), dim3(nsys), dim3(64), 0, c->stream, w, k0)
+#define IDAHIP_WP_SWITCH(F)                                                                                   \
+    switch (ns) {                                                                                              \
+        case 1: IDAHIP_WP_LAUNCH(F, 1); break;                                                                 \
+        case 2: IDAHIP_WP_LAUNCH(F, 2); break;                                                                 \
+        case 3: IDAHIP_WP_LAUNCH(F, 3); break;                                                                 \
+        case 4: IDAHIP_WP_LAUNCH(F, 4); break;                                                                 \
+        case 5: IDAHIP_WP_LAUNCH(F, 5); break;                                                                 \
+        case 6: IDAHIP_WP_LAUNCH(F, 6); break;                                                                 \
+        case 7: IDAHIP_WP_LAUNCH(F, 7); break;                                                                 \
+        default: IDAHIP_WP_LAUNCH(F, 8); break;                                                                \
+    }
             if (fast) {
-                hipLaunchKernelGGL((lu_wavepanel_kernel<true, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                hipLaunchKernelGGL((lu_wavepanel_kernel<true, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                IDAHIP_WP_SWITCH(true)
+                hipLaunchKernelGGL((lu_wavepanel_kernel<true, true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
             } else {
-                hipLaunchKernelGGL((lu_wavepanel_kernel<false, false>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-                hipLaunchKernelGGL((lu_wavepanel_kernel<false, true>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
+                IDAHIP_WP_SWITCH(false)
+                hipLaunchKernelGGL((lu_wavepanel_kernel<false, true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
             }
+#undef IDAHIP_WP_SWITCH
+#undef IDAHIP_WP_LAUNCH
         } else {
             // two 32-column panels; the first one's update reaches the second through a narrow (32-column) launch of the
             // trailing kernel

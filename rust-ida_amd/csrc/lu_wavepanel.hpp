@@ -32,6 +32,12 @@ namespace idahip {
 
 constexpr int WP_MAX_ROWS = 512;  // 8 slots of 64 lanes
 
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, soffset, 0);
+    return __hiloint2double((int)r.y, (int)r.x);
+}
+
 // A wave-uniform value as a per-lane value the optimiser cannot see through: `u == 0 ? a : b` then stays a pair of
 // v_cndmask instead of becoming a scalar branch around the update (a branch around 64 panel registers makes the
 // register allocator keep two copies of them).
@@ -40,8 +46,11 @@ __device__ __forceinline__ double opaque_vgpr(double u) {
     return u;
 }
 
-template <bool FMA, bool SLOWK>
-__global__ __launch_bounds__(64, SLOWK ? 1 : 2) void lu_wavepanel_kernel(LuWs w, const int k0) {
+// NS > 0: the number of slots (= ceil(live rows / 64)) as a compile-time constant -- the per-slot guards fold away and the
+// registers of the unused slots are never allocated (eight instantiations of the FAST kernel, one per super-panel of an
+// N = 512 factorisation); NS = 0: taken from the matrix size at run time (the SLOW kernel).
+template <bool FMA, bool SLOWK, int NS>
+__global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void lu_wavepanel_kernel(LuWs w, const int k0) {
     constexpr int BIG = 1 << 20;  // pstep of a row that is still live
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
@@ -53,14 +62,18 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : 2) void lu_wavepanel_kernel(LuWs w,
     long long* __restrict__ piv = w.piv + (long)b * w.pstride;
     double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
 
+    // buffer descriptor of this system's work matrix: loads with a 32-bit per-lane row offset + a scalar column offset, no
+    // vector address arithmetic (the matrix is n * n * 8 bytes <= 2 MiB)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, n * n * 8, 0x00020000);
     const int m = n - k0;                 // live rows, <= WP_MAX_ROWS
     const int wsp = m < 64 ? m : 64;      // columns of this super-panel
     const int lane = threadIdx.x;
-    const int nslots = (m + 63) >> 6;
+    const int nslots = NS > 0 ? NS : (m + 63) >> 6;
 
     __shared__ int ptab[64];  // owner of pivot k of this super-panel: lane | slot << 6
 
     int rowid[8], rpos[8], pstep[8];  // physical row, reference position, step at which the row became a pivot (BIG: live, -1: no row)
+    unsigned roff[8];                 // byte offset of the row inside a column of the work matrix
     static_for<0, 8>([&](auto st) {
         constexpr int S = decltype(st)::value;
         const int li = S * 64 + lane;
@@ -68,6 +81,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : 2) void lu_wavepanel_kernel(LuWs w,
         rowid[S] = has ? live[li] : 0;
         rpos[S] = has ? pos[rowid[S]] : 0x7fffffff;
         pstep[S] = has ? BIG : -1;
+        roff[S] = (unsigned)rowid[S] * 8u;
     });
 
     // ------------------------------------------------------------------------------------------------------------------
@@ -102,27 +116,20 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : 2) void lu_wavepanel_kernel(LuWs w,
         constexpr bool SLOW = decltype(slow_tag)::value;
         // ---- left-looking: the updates of the super-panel's earlier pivots, ascending k
         if (b8 > 0) {
-            double lk[8];
-            static_for<0, 8>([&](auto st) {
-                constexpr int S = decltype(st)::value;
-                lk[S] = (S < nslots) ? A[(long)k0 * n + rowid[S]] : 0.0;
-            });
-            int ow = ptab[0];
-#pragma unroll 1
-            for (int k = 0; k < b8; ++k) {
-                const int pl = __builtin_amdgcn_readfirstlane(ow) & 63, ps = __builtin_amdgcn_readfirstlane(ow) >> 6;
-                double lc[8];
+            // multipliers of column k0 + k for the rows of this lane: scalar column base + 32-bit row offset (no vector
+            // address arithmetic per load); two register sets used alternately, each loaded one step ahead of its use
+            auto load_l = [&](double (&l)[8], const int k) {
+                const int coloff = (k0 + k) * n * 8;  // byte offset of the column inside this system's matrix (< 2^31: n <= 512)
                 static_for<0, 8>([&](auto st) {
                     constexpr int S = decltype(st)::value;
-                    lc[S] = lk[S];
+                    // (unconditional: a slot without rows has offset 0 and reads row 0 -- one cached line for the whole wave, the
+                    // value is never used. A guarded load would leave the register's old value live on one path, and the compiler
+                    // then waits for every outstanding load before issuing the next one.)
+                    l[S] = buf_load_f64(rsrc, roff[S], coloff);
                 });
-                if (k + 1 < b8) {  // next step's multipliers and owner in flight behind this step's arithmetic
-                    static_for<0, 8>([&](auto st) {
-                        constexpr int S = decltype(st)::value;
-                        lk[S] = (S < nslots) ? A[(long)(k0 + k + 1) * n + rowid[S]] : 0.0;
-                    });
-                    ow = ptab[k + 1];
-                }
+            };
+            auto apply = [&](const double (&l)[8], const int k, const int ow) {
+                const int pl = __builtin_amdgcn_readfirstlane(ow) & 63, ps = __builtin_amdgcn_readfirstlane(ow) >> 6;
                 double uk[8];  // U entries of pivot row k in this block's columns, as they stand after the updates 0 .. k-1
                 switch (ps) {
 #define IDAHIP_WP_CASE(SV)                                                                 \
@@ -152,15 +159,32 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : 2) void lu_wavepanel_kernel(LuWs w,
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 if (SLOW) {
-                                    const double tn = upd<FMA>(x[S][j], ukv[j], lc[S]);
+                                    const double tn = upd<FMA>(x[S][j], ukv[j], l[S]);
                                     x[S][j] = (ukv[j] == 0.0) ? x[S][j] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
                                 } else {
-                                    x[S][j] = upd<FMA>(x[S][j], uk[j], lc[S]);
+                                    x[S][j] = upd<FMA>(x[S][j], uk[j], l[S]);
                                 }
                             }
                         }
                     }
                 });
+            };
+            // the block's loads are complete before the loop starts: the compiler's wait-count bookkeeping would otherwise carry
+            // "x may still be in flight" around the loop and wait for the freshly issued multiplier loads at every use of x
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            double la[8], lb[8];
+            load_l(la, 0);
+            int owa = ptab[0], owb = 0;
+#pragma unroll 1
+            for (int k = 0; k < b8; k += 2) {  // b8 is a multiple of 8: always an even number of steps
+                load_l(lb, k + 1);
+                owb = ptab[k + 1];
+                apply(la, k, owa);
+                if (k + 2 < b8) {
+                    load_l(la, k + 2);
+                    owa = ptab[k + 2];
+                }
+                apply(lb, k + 1, owb);
             }
         }
         // ---- the block's own pivot steps

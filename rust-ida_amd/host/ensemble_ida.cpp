@@ -32,7 +32,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <string>
 #include <vector>
@@ -138,9 +140,20 @@ int efail(idaens* e, int code, const char* fmt, ...) {
     return code;
 }
 
+// IDAENS_PROFILE=1 in the environment: wall time inside device-library calls vs in this file's own host logic, printed
+// by idaens_destroy (development aid for the host/device balance of a round)
+static double g_prof_dev = 0.0, g_prof_t0 = -1.0;
+static const bool g_prof = std::getenv("IDAENS_PROFILE") != nullptr;
+static double prof_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 #define ENS_CALL(e, call)                                                                                   \
     do {                                                                                                    \
+        const double t0__ = g_prof ? prof_now() : 0.0;                                                      \
         int rc__ = (call);                                                                                  \
+        if (g_prof) g_prof_dev += prof_now() - t0__;                                                        \
         if (rc__ < 0) return efail((e), rc__, "%s failed (%d): %s", #call, rc__, idahip_last_error((e)->ctx)); \
     } while (0)
 
@@ -994,6 +1007,7 @@ extern "C" {
 int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const double* hYP0) {
     if (!out || !ctx || !hYY0 || !hYP0) return -1;
     idaens* e = new idaens();
+    if (g_prof && g_prof_t0 < 0.0) g_prof_t0 = prof_now();
     e->ctx = ctx;
     e->n = idahip_n(ctx);
     e->batch = idahip_batch(ctx);
@@ -1014,6 +1028,11 @@ int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const doubl
 }
 
 int idaens_destroy(idaens* e) {
+    if (g_prof && e) {
+        const double tot = prof_now() - g_prof_t0;
+        std::fprintf(stderr, "[idaens profile] rounds %lld: in device-library calls %.3f s, host logic + idle %.3f s (since the first create)\n",
+                     (long long)e->total_rounds, g_prof_dev, tot - g_prof_dev);
+    }
     delete e;
     return 0;
 }
