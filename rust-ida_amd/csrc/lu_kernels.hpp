@@ -755,7 +755,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int pl = 4 * (lane & 15) + (lane >> 4);  // LDS slot of column `lane`: columns q, q+16, q+32, q+48 sit together
 
-    __shared__ __align__(16) double Us[NB][64];      // U12, columns permuted by pl
+#ifndef IDAHIP_US_PAD
+#define IDAHIP_US_PAD 2
+#endif
+    // U12, columns permuted by pl. Rows padded by two doubles (still 16-byte aligned for ds_read_b128): the column reads of
+    // the store to the factors below (lane = row) then spread over 8 bank groups instead of hitting one
+    __shared__ __align__(16) double Us[NB][64 + IDAHIP_US_PAD];
     __shared__ __align__(16) double Ls[KC][64];      // prologue: L11 staging; update loop: 4 wave-private [KC][16] strips
     __shared__ unsigned short s_live[MAXROWS];
     __shared__ int s_anyzero;

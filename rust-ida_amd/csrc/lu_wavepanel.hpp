@@ -30,7 +30,14 @@
 
 namespace idahip {
 
-constexpr int WP_MAX_ROWS = 512;  // 8 slots of 64 lanes
+constexpr int WP_MAX_ROWS = 512;
+#ifndef IDAHIP_WP_RING
+#define IDAHIP_WP_RING 0
+#endif
+// depth (in pivots) of the multiplier prefetch ring of lu_wavepanel_kernel for a given slot count
+// (measured, 1240 matrices per call: rings of 4 and 8 change nothing for 1-5 slots and cost 4-8 % for 6-7 -- the loop waits
+// for instruction issue, not for the loads; IDAHIP_WP_RING=1 builds the deep rings for another look)
+constexpr int WP_RING(int ns) { return !IDAHIP_WP_RING ? 2 : (ns >= 1 && ns <= 2) ? 8 : (ns >= 3 && ns <= 7) ? 4 : 2; }  // 8 slots of 64 lanes
 
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -69,12 +76,13 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
     const int wsp = m < 64 ? m : 64;      // columns of this super-panel
     const int lane = threadIdx.x;
     const int nslots = NS > 0 ? NS : (m + 63) >> 6;
+    constexpr int NSC = NS > 0 ? NS : 8;  // slots that can hold rows: every loop over slots stops there
 
     __shared__ int ptab[64];  // owner of pivot k of this super-panel: lane | slot << 6
 
     int rowid[8], rpos[8], pstep[8];  // physical row, reference position, step at which the row became a pivot (BIG: live, -1: no row)
     unsigned roff[8];                 // byte offset of the row inside a column of the work matrix
-    static_for<0, 8>([&](auto st) {
+    static_for<0, NSC>([&](auto st) {
         constexpr int S = decltype(st)::value;
         const int li = S * 64 + lane;
         const bool has = li < m;
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
     // one block of `WB` (= 8 unless PARTIAL) columns starting at column b8 of the super-panel; x = the block, in registers.
     // returns 0 = done, 1 = zero pivot (info set), 2 = FAST assumptions violated (nothing stored)
     auto load_block = [&](double (&x)[8][8], const int b8, const int wb) {
-        static_for<0, 8>([&](auto st) {
+        static_for<0, NSC>([&](auto st) {
             constexpr int S = decltype(st)::value;
             if (S < nslots) {
                 const double* __restrict__ src = A + (long)(k0 + b8) * n + rowid[S];
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
         });
     };
     auto store_block = [&](const double (&x)[8][8], const int b8, const int wb) {
-        static_for<0, 8>([&](auto st) {
+        static_for<0, NSC>([&](auto st) {
             constexpr int S = decltype(st)::value;
             if (S < nslots && pstep[S] >= 0) {
                 double* __restrict__ dst = A + (long)(k0 + b8) * n + rowid[S];
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             // address arithmetic per load); two register sets used alternately, each loaded one step ahead of its use
             auto load_l = [&](double (&l)[8], const int k) {
                 const int coloff = (k0 + k) * n * 8;  // byte offset of the column inside this system's matrix (< 2^31: n <= 512)
-                static_for<0, 8>([&](auto st) {
+                static_for<0, NSC>([&](auto st) {
                     constexpr int S = decltype(st)::value;
                     // (unconditional: a slot without rows has offset 0 and reads row 0 -- one cached line for the whole wave, the
                     // value is never used. A guarded load would leave the register's old value live on one path, and the compiler
@@ -132,19 +140,21 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
                 const int pl = __builtin_amdgcn_readfirstlane(ow) & 63, ps = __builtin_amdgcn_readfirstlane(ow) >> 6;
                 double uk[8];  // U entries of pivot row k in this block's columns, as they stand after the updates 0 .. k-1
                 switch (ps) {
-#define IDAHIP_WP_CASE(SV)                                                                 \
-    case SV:                                                                               \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) uk[j] = readlane_f64(x[SV][j], pl); \
+#define IDAHIP_WP_CASE(SV)                                                                     \
+    case SV:                                                                                   \
+        if constexpr (SV < NSC) {                                                              \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) uk[j] = readlane_f64(x[SV][j], pl); \
+        }                                                                                      \
         break;
-                    IDAHIP_WP_CASE(0)
                     IDAHIP_WP_CASE(1)
                     IDAHIP_WP_CASE(2)
                     IDAHIP_WP_CASE(3)
                     IDAHIP_WP_CASE(4)
                     IDAHIP_WP_CASE(5)
                     IDAHIP_WP_CASE(6)
+                    IDAHIP_WP_CASE(7)
                     default:
-                        IDAHIP_WP_CASE(7)
+                        IDAHIP_WP_CASE(0)
 #undef IDAHIP_WP_CASE
                 }
                 double ukv[8];
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ukv[j] = opaque_vgpr(uk[j]);
                 }
-                static_for<0, 8>([&](auto st) {
+                static_for<0, NSC>([&](auto st) {
                     constexpr int S = decltype(st)::value;
                     if (S < nslots) {
                         if (pstep[S] > k) {  // the row was still live at step k (it is live now, or became a pivot later)
@@ -172,19 +182,26 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             // the block's loads are complete before the loop starts: the compiler's wait-count bookkeeping would otherwise carry
             // "x may still be in flight" around the loop and wait for the freshly issued multiplier loads at every use of x
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            double la[8], lb[8];
-            load_l(la, 0);
-            int owa = ptab[0], owb = 0;
+            // D register sets used in turn, each reloaded right after its use: D - 1 pivots' worth of arithmetic covers a load.
+            // A step is 16 * slots fp64 operations, a load from HBM about a microsecond: few slots want a deep ring, and have the
+            // registers for it. (A reload past the end of the range re-reads the last column; the value is never used.)
+            constexpr int D = WP_RING(NS);
+            double l[D][8];
+            int ow[D];
+            static_for<0, D>([&](auto dt) {
+                constexpr int d = decltype(dt)::value;
+                load_l(l[d], d);
+                ow[d] = ptab[d];
+            });
 #pragma unroll 1
-            for (int k = 0; k < b8; k += 2) {  // b8 is a multiple of 8: always an even number of steps
-                load_l(lb, k + 1);
-                owb = ptab[k + 1];
-                apply(la, k, owa);
-                if (k + 2 < b8) {
-                    load_l(la, k + 2);
-                    owa = ptab[k + 2];
-                }
-                apply(lb, k + 1, owb);
+            for (int k = 0; k < b8; k += D) {  // b8 is a multiple of 8, D divides 8
+                static_for<0, D>([&](auto dt) {
+                    constexpr int d = decltype(dt)::value;
+                    apply(l[d], k + d, ow[d]);
+                    const int kn = (k + d + D < b8) ? k + d + D : b8 - 1;
+                    load_l(l[d], kn);
+                    ow[d] = ptab[kn];
+                });
             }
         }
         // ---- the block's own pivot steps
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             // candidate key of a live row: the bit pattern of |a| with the always-clear sign bit set (0 = no candidate);
             // NaN only wins at position kc (dense.rs:111-117 scan semantics)
             unsigned kh[8], kl[8];
-            static_for<0, 8>([&](auto st) {
+            static_for<0, NSC>([&](auto st) {
                 constexpr int S = decltype(st)::value;
                 const double v = x[S][kk];
                 unsigned h = (unsigned)__double2hiint(v) | 0x80000000u, l = (unsigned)__double2loint(v);
@@ -214,13 +231,13 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             });
             unsigned lm = kh[0];
 #pragma unroll
-            for (int s = 1; s < 8; ++s) lm = kh[s] > lm ? kh[s] : lm;
+            for (int s = 1; s < NSC; ++s) lm = kh[s] > lm ? kh[s] : lm;
             const unsigned mh = wave_max_u32<false>(lm);
             if (!SLOW) special = special || mh >= 0xfff00000u;
             // is the maximum of the high words attained by one row only? (the common case: the arg-max is found)
             int cnt = 0, slot = 0;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < NSC; ++s) {
                 const bool e = kh[s] == mh;
                 cnt += e ? 1 : 0;
                 slot = e ? s : slot;
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
                 unsigned bl = 0u;
                 int bp_ = 0x7fffffff, bs = 0;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < NSC; ++s) {
                     const bool e = kh[s] == mh;
                     const bool better = e && (kl[s] > bl || (kl[s] == bl && rpos[s] < bp_) || bp_ == 0x7fffffff);
                     bl = better ? kl[s] : bl;
@@ -253,21 +270,23 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             double u[8];
             int bp = 0, pr = 0;
             switch (ps) {
-#define IDAHIP_WP_CASE(SV)                                                                         \
-    case SV:                                                                                       \
-        _Pragma("unroll") for (int j = kk; j < 8; ++j) u[j] = readlane_f64(x[SV][j], pl);         \
-        bp = __builtin_amdgcn_readlane(rpos[SV], pl);                                              \
-        pr = __builtin_amdgcn_readlane(rowid[SV], pl);                                             \
+#define IDAHIP_WP_CASE(SV)                                                                             \
+    case SV:                                                                                           \
+        if constexpr (SV < NSC) {                                                                      \
+            _Pragma("unroll") for (int j = kk; j < 8; ++j) u[j] = readlane_f64(x[SV][j], pl);         \
+            bp = __builtin_amdgcn_readlane(rpos[SV], pl);                                              \
+            pr = __builtin_amdgcn_readlane(rowid[SV], pl);                                             \
+        }                                                                                              \
         break;
-                IDAHIP_WP_CASE(0)
                 IDAHIP_WP_CASE(1)
                 IDAHIP_WP_CASE(2)
                 IDAHIP_WP_CASE(3)
                 IDAHIP_WP_CASE(4)
                 IDAHIP_WP_CASE(5)
                 IDAHIP_WP_CASE(6)
+                IDAHIP_WP_CASE(7)
                 default:
-                    IDAHIP_WP_CASE(7)
+                    IDAHIP_WP_CASE(0)
 #undef IDAHIP_WP_CASE
             }
             bool go = active;
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
                     prow[kc] = pr;
                     ptab[kstep] = pl | (ps << 6);
                 }
-                static_for<0, 8>([&](auto st) {
+                static_for<0, NSC>([&](auto st) {
                     constexpr int S = decltype(st)::value;
                     if (pstep[S] == BIG && rpos[S] == kc) rpos[S] = bp;  // the row that sat at position k moves to the pivot's old position
                     if (lane == pl && ps == S) {
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
 #pragma unroll
                 for (int j = kk + 1; j < 8; ++j) uv[j] = opaque_vgpr(u[j]);
             }
-            static_for<0, 8>([&](auto st) {
+            static_for<0, NSC>([&](auto st) {
                 constexpr int S = decltype(st)::value;
                 if (S < nslots) {
                     if (pstep[S] == BIG && go) {
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
             // verify the assumptions: no special value among the candidates, no exact zero in a pivot row of this block's
             // columns (conservative: the multipliers of the block's own pivot rows are looked at too)
             bool z = false;
-            static_for<0, 8>([&](auto st) {
+            static_for<0, NSC>([&](auto st) {
                 constexpr int S = decltype(st)::value;
                 bool zz = false;
 #pragma unroll
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
         for (int k = 0; k < bstart; ++k) {
             const int kc = k0 + k;
             const int bp = (int)piv[kc], pr = prow[kc];
-            static_for<0, 8>([&](auto st) {
+            static_for<0, NSC>([&](auto st) {
                 constexpr int S = decltype(st)::value;
                 if (pstep[S] == BIG && rpos[S] == kc) rpos[S] = bp;
                 const bool mine = pstep[S] >= 0 && rowid[S] == pr;
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
 
     // ---- positions, transposed L11 (multipliers of the pivot rows, read back from the matrix), compacted live list
     __syncthreads();  // the stores above (work matrix, prow) are visible to every lane of the wave
-    static_for<0, 8>([&](auto st) {
+    static_for<0, NSC>([&](auto st) {
         constexpr int S = decltype(st)::value;
         if (pstep[S] >= 0) pos[rowid[S]] = rpos[S];
     });
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
         }
     }
     int base = 0;
-    static_for<0, 8>([&](auto st) {
+    static_for<0, NSC>([&](auto st) {
         constexpr int S = decltype(st)::value;
         const bool al = pstep[S] == BIG;
         const unsigned long long bal = __ballot(al);
