@@ -96,6 +96,46 @@ def test_lu_and_solve_random_bit_exact(n):
     assert np.array_equal(x, x_o)
 
 
+@pytest.mark.parametrize("n", [128, 129, 191, 192, 193, 320, 449, 511, 513, 640, 1000, 1024])
+def test_lu_sizes_around_the_super_panel_and_slot_boundaries(n):
+    """64-column super-panels, 64-row register slots of the wave-per-matrix panel kernel (<= 512 live rows), the two-rows-per-lane
+    panels above that: sizes on both sides of every boundary, one dense matrix and one with many exact zeros."""
+    rng = np.random.default_rng(5000 + n)
+    mats = rng.standard_normal((2, n, n))
+    mats[1][np.abs(mats[1]) < 0.9] = 0.0
+    mats[1] += np.diag(np.full(n, 4.0))
+    info_o, lu_o, piv_o = oracle_lu(mats)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(mats)
+    assert rc == 0 and np.array_equal(info, info_o)
+    assert np.array_equal(piv, piv_o)
+    assert np.array_equal(lu, lu_o)
+
+
+@pytest.mark.parametrize("n", [24, 100, 200, 600, 1100])
+def test_nan_and_infinity_follow_the_reference_scan(n):
+    """dense.rs:111-117 picks the pivot with `>` on absolute values: a NaN never wins a comparison, so it becomes the pivot only
+    when it already sits at position k, and an infinity wins like any large value (and then breeds NaNs). Pivots and the
+    zero-pivot verdict must match exactly; values bit for bit where they are numbers, NaN where the oracle has NaN (sign and
+    payload of a NaN are not part of the contract: x86 and the GPU generate different default NaNs)."""
+    rng = np.random.default_rng(77 + n)
+    mats = rng.standard_normal((6, n, n))
+    mats[0, 5, 5] = np.nan                      # NaN on the diagonal: the scan keeps it once column 5 is reached (if still there)
+    mats[1, n - 2, 3] = np.nan                  # NaN below the diagonal: never chosen in column 3, poisons its row
+    mats[2, 7, 2] = np.inf                      # +inf wins column 2
+    mats[3, n // 2, 0] = -np.inf                # -inf wins column 0
+    mats[4, 1, 1] = np.nan
+    mats[4, 9, 4] = np.inf
+    mats[4, 11, 4] = -np.inf                    # two infinities in one column: the first in scan order wins
+    mats[5, :, :] = np.where(rng.random((n, n)) < 0.02, np.nan, mats[5])
+    info_o, lu_o, piv_o = oracle_lu(mats)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(mats)
+    assert np.array_equal(info, info_o)
+    ok = info_o == 0
+    assert np.array_equal(piv[ok], piv_o[ok])
+    assert np.array_equal(np.isnan(lu[ok]), np.isnan(lu_o[ok]))
+    assert np.array_equal(lu[ok], lu_o[ok], equal_nan=True)
+
+
 @pytest.mark.parametrize("n", [1025, 1100, 1600, 2048])
 def test_lu_beyond_1024_rows(n):
     """More than 1024 rows: the leading super-panels run with eight 8-column panels and eight rows per lane (whatever
