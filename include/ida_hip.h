@@ -190,7 +190,7 @@ typedef enum {
     IDAHIP_K_SYS_JAC = 6, /* fused residual + Jacobian pass of idahip_nls_sys_setup */
     /* single kernels of the batched LU (timing level 2 only): every launch of the kernel is bracketed by its own pair of
      * events; `systems` counts matrices x launches */
-    IDAHIP_K_LU_PANEL = 7,    /* lu_wavepanel_kernel (variant 3: lu_panel2_kernel + narrow lu_trail_kernel) */
+    IDAHIP_K_LU_PANEL = 7,    /* lu_wavepanel_kernel (variant 3, or more than 512 live rows: lu_panel2_kernel / lu_panelr_kernel + narrow lu_trail_kernel) */
     IDAHIP_K_LU_TRAIL = 8,    /* lu_trail64w_kernel */
     IDAHIP_K_LU_FINALIZE = 9, /* lu_finalize_kernel */
     IDAHIP_K_COUNT = 10

@@ -37,6 +37,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         if (n - k0 > LU_MAX_N) {
             // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
             // update of the rest of the super-panel
+            KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             constexpr int NBS = 8;
             const int cend = (k0 + 64 < n) ? k0 + 64 : n;
             const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;

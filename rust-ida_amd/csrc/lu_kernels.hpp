@@ -569,20 +569,38 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     __shared__ __align__(16) double Ls[2][NB][LD];
     __shared__ unsigned short s_live[MAXROWS];  // row indices < 65536
     __shared__ int s_anyzero;
+    __shared__ unsigned s_kmask;  // slow path: bit k set = pivot row k has a non-zero entry in this column block
+    __shared__ int s_nz[4];       // per wave: a non-zero entry among the pivot-row entries it gathered
 
     for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
     // 1. gather the pivot rows of this column block (wave-uniform k per pass -> prow[k] is a scalar load)
+    bool nz = false;
 #pragma unroll
     for (int pass = 0; pass < NB / 4; ++pass) {
         const int k = pass * 4 + wave;
         const int pr = ldc(prow + k);
-        Us[k][lane] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+        const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+        nz = nz || (g != 0.0);
+        Us[k][lane] = g;
     }
+    if (lane == 0) s_nz[wave] = 0;
+    if (__ballot(nz) != 0ull && lane == 0) s_nz[wave] = 1;
     if (t == 0) s_anyzero = 0;
     // transposed L11 into the (still idle) tile buffer: a triangular-solve step reads its multipliers as LDS broadcasts
     // instead of waiting on one scalar load per step
     for (int e = t; e < NB * NB; e += 256) Ls[0][e / NB][e % NB] = l11[(e / NB) * w.l11ld + (e % NB)];
     __syncthreads();
+    if ((s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3]) == 0) {
+        // the pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
+        // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
+        double* __restrict__ O = w.out + (long)b * w.ostride;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            if (cc < ncols && lane < NB) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][cc];
+        }
+        return;
+    }
 
     // 3. rank-NB update of every 64-row tile of live rows, software-pipelined: while tile rt is computed from LDS the
     //    multipliers and the C tile of tile rt+1 are already in flight; one raw barrier per tile (LDS visibility only --
@@ -646,13 +664,24 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) Us[k][lane] = u[k];
-        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
+        if (__ballot(anyz) != 0ull) {
+            // dense.rs:148 skips the whole row update when a_kj == 0: a pivot row that is zero across this column block
+            // contributes nothing here -- banded Jacobians (heat equation) have almost only such rows
+            unsigned km = 0u;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) km |= (__ballot(real && u[k] != 0.0) != 0ull) ? (1u << k) : 0u;
+            if (lane == 0) {
+                s_anyzero = 1;
+                s_kmask = km;
+            }
+        }
         load_tile(0, lreg, creg, crow, rok);
     } else {
         load_tile(0, lreg, creg, crow, rok);  // waves 1-3: first tile in flight while wave 0 solves for U12
     }
     __syncthreads();
     const bool slow = s_anyzero != 0;
+    const unsigned kmask = slow ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask) : 0xffffffffu;
     // The solved pivot rows are final and nothing reads them in the work matrix again: they go straight to their place in
     // the factors -- pivot k of this panel is row k0 + k of the reference layout, so a column's NB entries are one
     // contiguous store (one row per lane) instead of NB eight-byte stores into NB different sectors of the work matrix;
@@ -666,6 +695,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
         }
     }
 
+    if (kmask == 0u) return;  // (uniform over the workgroup) nothing to subtract anywhere in this column block
 #pragma unroll 1
     for (int rt = 0; rt < ntiles; ++rt) {
         const int buf = rt & 1;
@@ -697,8 +727,8 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
                     for (int i = 0; i < 4; ++i) c[i][j] -= uv[j] * lv[i];  // dense.rs:151, unfused
             }
         } else {
-#pragma unroll 4
-            for (int k = 0; k < NB; ++k) {
+            for (unsigned mk = kmask; mk != 0u; mk &= mk - 1u) {  // ascending k, rows that are zero across the block skipped
+                const int k = __builtin_ctz(mk);
                 double lv[4], uv[CJ];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lv[i] = Ls[buf][k][tx + 16 * i];
@@ -764,14 +794,21 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     __shared__ __align__(16) double Ls[KC][64];      // prologue: L11 staging; update loop: 4 wave-private [KC][16] strips
     __shared__ unsigned short s_live[MAXROWS];
     __shared__ int s_anyzero;
+    __shared__ int s_nz[4];          // per wave: a non-zero entry among the pivot-row entries it gathered
+    __shared__ unsigned s_kmask[2];  // slow path: bit k of word R0 / 32 set = pivot row R0 + k has a non-zero entry in this column block
 
     for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+    bool nz = false;
 #pragma unroll
     for (int pass = 0; pass < NB / 4; ++pass) {
         const int k = pass * 4 + wave;
         const int pr = ldc(prow + k);
-        Us[k][pl] = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+        const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+        nz = nz || (g != 0.0);
+        Us[k][pl] = g;
     }
+    if (lane == 0) s_nz[wave] = 0;
+    if (__ballot(nz) != 0ull && lane == 0) s_nz[wave] = 1;
     if (t == 0) s_anyzero = 0;
     auto stage_l11 = [&](const int R0) {
 #pragma unroll
@@ -782,6 +819,17 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     };
     stage_l11(0);
     lds_barrier();
+    if ((s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3]) == 0) {
+        // the 64 pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
+        // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
+        double* __restrict__ O = w.out + (long)b * w.ostride;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
+        }
+        return;
+    }
 
     // ---- this lane's share of a strip: rows a + 4i, columns q + 16j
     const int a = lane & 3, q = lane >> 2;
@@ -847,7 +895,19 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k) Us[R0 + k][pl] = u[k];
-        if (__ballot(anyz) != 0ull && lane == 0) s_anyzero = 1;
+        // dense.rs:148 skips the whole row update when a_kj == 0: a pivot row that is zero across this column block
+        // contributes nothing to it -- banded Jacobians (heat equation) have almost only such rows. (The mask is only read
+        // on the select path, i.e. when some entry of the block is an exact zero.)
+        unsigned km = 0xffffffffu;
+        if (__ballot(anyz) != 0ull || s_anyzero != 0) {
+            km = 0u;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) km |= (__ballot(real && u[k] != 0.0) != 0ull) ? (1u << k) : 0u;
+        }
+        if (lane == 0) {
+            s_kmask[R0 / KC] = km;
+            if (__ballot(anyz) != 0ull) s_anyzero = 1;
+        }
     };
 
     if (wave == 0) trsm32(0);
@@ -906,6 +966,9 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
         }
     }
+    const unsigned kmask0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[0]);
+    const unsigned kmask1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[1]);
+    if (slow && (kmask0 | kmask1) == 0u) return;  // (uniform over the workgroup) U12 of this block is all zeros: nothing to subtract
     double (*__restrict__ Lw)[16] = reinterpret_cast<double (*)[16]>(&Ls[0][0] + wave * (KC * 16));
 
     auto chunk = [&](double (&c)[4][4], const int kbase) {
@@ -948,8 +1011,8 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             }
 #endif
         } else {
-#pragma unroll 4
-            for (int k = 0; k < KC; ++k) {
+            for (unsigned mk = kbase == 0 ? kmask0 : kmask1; mk != 0u; mk &= mk - 1u) {  // ascending k, all-zero pivot rows skipped
+                const int k = __builtin_ctz(mk);
                 double lv[4], uv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lv[i] = Lw[k][4 * a + i];
