@@ -454,6 +454,36 @@ def test_user_problem_through_host_callbacks_reproduces_the_roberts_example():
     ens.close()
 
 
+def test_failing_user_callback_aborts_the_call_with_an_error():
+    """A residual / Jacobian callback that fails (non-zero return; here: a Python exception caught by the binding's thunk)
+    aborts the entry point that called it with -7 and a message naming the system; nothing unwinds across the C boundary. A
+    newton_iter2 call on a host-callback ctx is refused (the fused iterations need a device residual)."""
+    import idahip
+    n, B = 3, 2
+    calls = {"res": 0}
+
+    def res(sys, t, y, yp):
+        calls["res"] += 1
+        if sys == 1:
+            raise RuntimeError("user code failed")
+        return [y[0] - 1.0, y[1] - 2.0, yp[2]]
+
+    def jac(sys, t, cj, y, yp, r):
+        raise RuntimeError("user code failed")
+
+    ctx = idahip.Ctx("host_callback", n, B)
+    with pytest.raises(idahip.IdaHipError, match="set_host_problem has not been called"):
+        ctx.nls_sys(0.0, 1.0, True)
+    ctx.set_host_problem(res, jac)
+    ctx.set_tolerances(1e-6, 1e-8)
+    ctx.nls_sys(0.0, 1.0, True, idx=[0])                        # system 0 alone is fine
+    with pytest.raises(idahip.IdaHipError, match="residual function failed for system 1"):
+        ctx.nls_sys(0.0, 1.0, True)
+    with pytest.raises(idahip.IdaHipError, match="Jacobian function failed for system 0"):
+        ctx.nls_lsetup(0.0, 1.0, idx=[0])
+    assert calls["res"] >= 3
+
+
 @pytest.mark.parametrize("kind", ["linear_dense", "lorenz63", "heat1d", "roberts"])
 def test_fused_first_two_newton_iterations_change_nothing(kind):
     """SURVEY 8(f)-2, first slice: with idahip_newton_iter2 the first two Newton iterations of a solve and their convergence
