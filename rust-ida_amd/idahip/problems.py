@@ -86,7 +86,6 @@ def _fill_range(args):
     return hi - lo
 
 
-_KEEP = []  # shared memory blocks behind arrays handed out by linear_dense(procs > 1): alive as long as the process
 
 
 def linear_dense(n=512, batch=4096, first=0, procs=1, nthreads=1):
@@ -124,23 +123,31 @@ def linear_dense(n=512, batch=4096, first=0, procs=1, nthreads=1):
     if procs > 1 and batch >= 2 * procs:
         # worker processes forked from a clean fork server (itself started by exec, so none of them inherits this
         # process's threads, locks or -- if the GPU is already in use here -- ROCm runtime); results come back through
-        # named shared memory, unlinked as soon as the workers are done
+        # named shared memory, a slice of the batch at a time: a slice is copied into ordinary memory and its blocks are
+        # unlinked before the next one is created, so that at most ~2 GB per process sit in /dev/shm however large the
+        # batch is (eight ranks of a node generate at the same time)
         import multiprocessing as mp
         from multiprocessing import shared_memory
-        blocks = [shared_memory.SharedMemory(create=True, size=max(8, int(np.prod(sh)) * 8)) for sh in shapes]
-        try:
-            step = max(1, batch // (procs * 4))
-            names = [b.name for b in blocks]
-            jobs = [(n, first, lo, min(batch, lo + step), True, names, shapes) for lo in range(0, batch, step)]
-            ctx = mp.get_context("forkserver")
-            ctx.set_forkserver_preload(["numpy"])
-            with ctx.Pool(procs) as pool:
-                assert sum(pool.map(_fill_range, jobs)) == batch
-        finally:
-            for b in blocks:
-                b.unlink()
-        arrays = [np.ndarray(sh, dtype=np.float64, buffer=b.buf) for sh, b in zip(shapes, blocks)]
-        _KEEP.extend(blocks)
+        arrays = [np.empty(sh) for sh in shapes]
+        slice_systems = max(2 * procs, min(batch, (1 << 31) // max(1, 16 * n * n)))  # A and B of a slice: <= 2 GiB
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["numpy"])
+        with ctx.Pool(procs) as pool:
+            for s0 in range(0, batch, slice_systems):
+                cnt = min(slice_systems, batch - s0)
+                sl_shapes = [(cnt,) + sh[1:] for sh in shapes]
+                blocks = [shared_memory.SharedMemory(create=True, size=max(8, int(np.prod(sh)) * 8)) for sh in sl_shapes]
+                try:
+                    step = max(1, cnt // (procs * 4))
+                    names = [b.name for b in blocks]
+                    jobs = [(n, first + s0, lo, min(cnt, lo + step), True, names, sl_shapes) for lo in range(0, cnt, step)]
+                    assert sum(pool.map(_fill_range, jobs)) == cnt
+                    for dst, sh, b in zip(arrays, sl_shapes, blocks):
+                        dst[s0:s0 + cnt] = np.ndarray(sh, dtype=np.float64, buffer=b.buf)
+                finally:
+                    for b in blocks:
+                        b.close()
+                        b.unlink()
     else:
         arrays = [np.empty(sh) for sh in shapes]
         _SHARED["arrays"] = arrays
