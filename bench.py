@@ -133,19 +133,41 @@ class Runner:
     (Ida::new from its initial conditions) and starts over at once. The batch never drains: every lock-step round works on
     every system, each somewhere else in its integration."""
 
-    STAGGER = 96   # the systems' first starts are spread over this many rounds (about one integration)
-    SPIN_UP = 200  # untimed rounds before the warm-up: the stagger plus one more integration
+    STAGGER = None  # rounds over which the systems' first starts are spread; None: one typical integration (calibrated)
+    SPIN_UP = 200   # untimed rounds before the warm-up: the stagger plus at least one more integration
+    CALIBRATION_SYSTEMS = 128
+
+    @staticmethod
+    def integration_length(prob, device, nsample):
+        """Median number of lock-step rounds (step attempts) an integration of this workload takes, measured on the device
+        on the first `nsample` systems. The first starts are spread over exactly this many rounds: with a shorter or longer
+        ramp some phases of an integration are populated twice as densely as others and the load per round (the number of
+        matrices to factorise above all) oscillates with the integration's period -- +-6 % between 20-round windows with the
+        96 rounds of round 1, +-2 % with the calibrated 62 (tools/round_profile.py)."""
+        import idahip
+        from idahip import problems
+        ns = min(nsample, prob["yy0"].shape[0])
+        sub = {k: (v[:ns] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == prob["yy0"].shape[0] else v) for k, v in prob.items()}
+        ctx = problems.make_ctx(sub, device=device)
+        ens = idahip.Ensemble(ctx, sub["yy0"], sub["yp0"])
+        status, _, reached = ens.solve_schedule(sub["touts"])
+        assert (status == 0).all() and (reached == len(sub["touts"])).all()
+        att = ens.counter("n_attempts")
+        ens.close()
+        ctx.close()
+        return max(1, int(round(float(np.median(att)))))
 
     def __init__(self, prob, device):
         import idahip
         from idahip import problems
         self.prob = prob
+        self.stagger = self.STAGGER if self.STAGGER is not None else self.integration_length(prob, device, self.CALIBRATION_SYSTEMS)
         self.ctx = problems.make_ctx(prob, device=device)
         self.ens = idahip.Ensemble(self.ctx, prob["yy0"], prob["yp0"])
         if TIME_ALL:
             self.ctx.timing(2)
             self.ctx.timing_reset()
-        self.ens.stream(prob["touts"], self.SPIN_UP, stagger_rounds=self.STAGGER)
+        self.ens.stream(prob["touts"], max(self.SPIN_UP, 3 * self.stagger), stagger_rounds=self.stagger)
 
     def total_iters(self):
         return self.ens.total_newton_iters()
@@ -440,6 +462,9 @@ def main():
             "lu_plus_solve": lu_plus_solve(tim, args.n, "unfused", dense=args.workload != "heat1d") if args.n > 8 else None,
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),
+            "stream": {"stagger_rounds": run.stagger, "spin_up_rounds": max(Runner.SPIN_UP, 3 * run.stagger),
+                       "note": "first starts spread over one median integration length (rounds), measured on the device on the "
+                               "first %d systems before the stream starts; then the untimed spin-up, W warm-up and K timed rounds" % Runner.CALIBRATION_SYSTEMS},
         }
         if unfused is not None:
             out["newton_fusion"] = {"value_with_host_ctest_every_iteration": unfused, "unit": "Newton iters/s",
