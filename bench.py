@@ -194,11 +194,12 @@ class Runner:
             self.ctx.timing(0)
         return tim
 
-    def whole_pass(self, variant=4, level=0):
+    def whole_pass(self, variant=4, level=0, fused=1):
         """SURVEY 8(d): the whole ensemble from fresh state (Ida::new for every system) through its output schedule."""
         import idahip
         self.ctx.set_lu_variant(variant)
         ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
+        ens.set_fused_newton(fused)
         self.ctx.timing(level)
         self.ctx.timing_reset()
         self.sync()
@@ -351,25 +352,13 @@ def main():
     if TIME_ALL:
         tim = tim2  # the timers were never reset: both are totals over every launch of the process
 
-    unfused = None
-    if world == 1 and not args.no_extras:
-        # the same K steps with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
-        # device-side convergence tests (first slice); results are identical, only the pace changes
-        run.ens.set_fused_newton(0)
-        for _ in range(max(2, args.warmup // 2)):
-            run.step()
-        run.sync()
-        it1, t1 = run.total_iters(), time.perf_counter()
-        for _ in range(args.steps):
-            run.step()
-        run.sync()
-        unfused = (run.total_iters() - it1) / (time.perf_counter() - t1)
-        run.ens.set_fused_newton(1)
-
     extras = None
     if world == 1 and not args.no_extras:
         passes = [run.whole_pass(4) for _ in range(3)]
         rates = [p["iters"] / p["seconds"] for p in passes]
+        # the same passes with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
+        # device-side convergence tests (first slice); identical work and results, only the pace changes
+        unfused_rates = [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, fused=0)) for _ in range(3)]
         fast = run.whole_pass(5, level=1)
         differ = int((fast["counts"] != passes[0]["counts"]).any(axis=0).sum())
         rel = float(np.abs(fast["yy"] - passes[0]["yy"]).max() / max(1e-300, np.abs(passes[0]["yy"]).max()))
@@ -379,6 +368,10 @@ def main():
                            "seconds_median": statistics.median(p["seconds"] for p in passes),
                            "protocol": "SURVEY 8(d): every system from fresh state through its whole output schedule, exact LU, "
                                        "median of 3 passes, wall time of the pass with inputs resident"},
+            "newton_fusion": {"whole_pass_value_with_host_ctest_every_iteration": statistics.median(unfused_rates), "unit": "Newton iters/s",
+                              "note": "`value` and `whole_pass` run with idahip_newton_iter2 (first two Newton iterations and their "
+                                      "convergence tests in one device call); this is the whole pass with one host round trip per "
+                                      "iteration instead: same work, same results, median of 3 passes"},
             "fast_vs_exact": {"fast_whole_pass_value": fast["iters"] / fast["seconds"], "unit": "Newton iters/s",
                               "systems": int(passes[0]["counts"].shape[1]), "systems_with_different_counts": differ,
                               "counts_compared": ["nst", "netf", "ncfn", "nni", "nsetups", "kused"],
@@ -466,10 +459,6 @@ def main():
                        "note": "first starts spread over one median integration length (rounds), measured on the device on the "
                                "first %d systems before the stream starts; then the untimed spin-up, W warm-up and K timed rounds" % Runner.CALIBRATION_SYSTEMS},
         }
-        if unfused is not None:
-            out["newton_fusion"] = {"value_with_host_ctest_every_iteration": unfused, "unit": "Newton iters/s",
-                                    "note": "`value` runs with idahip_newton_iter2 (first two iterations + convergence tests in one "
-                                            "device call); this is the same stream with one host round trip per iteration"}
         if extras:
             out.update(extras)
         if TIME_ALL:
