@@ -172,11 +172,14 @@ class Runner:
     def total_iters(self):
         return self.ens.total_newton_iters()
 
-    def step(self):
-        """Exactly one lock-step round."""
+    def steps(self, k):
+        """Exactly k lock-step rounds (one step attempt of every system of the batch each), in one call: the host stepper runs
+        its k rounds back to back, the device-resident stepper of the small problems runs them inside one launch."""
+        if k <= 0:
+            return
         before = self.ens.total_rounds()
-        self.ens.stream(self.prob["touts"], 1)
-        assert self.ens.total_rounds() == before + 1
+        self.ens.stream(self.prob["touts"], k)
+        assert self.ens.total_rounds() == before + k
 
     def sync(self):
         self.ctx._chk(self.ctx.H.idahip_sync(self.ctx.h), "sync")
@@ -186,20 +189,20 @@ class Runner:
         if not TIME_ALL:
             self.ctx.timing(level)
             self.ctx.timing_reset()
-        for _ in range(k):
-            self.step()
+        self.steps(k)
         self.sync()
         tim = self.ctx.timing_get()
         if not TIME_ALL:
             self.ctx.timing(0)
         return tim
 
-    def whole_pass(self, variant=4, level=0, fused=1):
+    def whole_pass(self, variant=4, level=0, fused=1, device_ctl=1):
         """SURVEY 8(d): the whole ensemble from fresh state (Ida::new for every system) through its output schedule."""
         import idahip
         self.ctx.set_lu_variant(variant)
         ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
         ens.set_fused_newton(fused)
+        ens.set_device_controller(device_ctl)
         self.ctx.timing(level)
         self.ctx.timing_reset()
         self.sync()
@@ -332,13 +335,11 @@ def main():
     prob.pop("B", None)
 
     # ---- the number: W warm-up steps, then exactly K steps between barriers, no timers inside
-    for _ in range(args.warmup):
-        run.step()
+    run.steps(args.warmup)
     barrier()
     it0 = run.total_iters()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run.step()
+    run.steps(args.steps)
     run.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -372,6 +373,13 @@ def main():
                               "note": "`value` and `whole_pass` run with idahip_newton_iter2 (first two Newton iterations and their "
                                       "convergence tests in one device call); this is the whole pass with one host round trip per "
                                       "iteration instead: same work, same results, median of 3 passes"},
+            "device_controller": None if args.n > 8 else {
+                "whole_pass_value_with_the_host_stepper": statistics.median(
+                    [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, device_ctl=0)) for _ in range(3)]),
+                "unit": "Newton iters/s",
+                "note": "`value` and `whole_pass` run with the device-resident stepper (idahip_tiny_solve: the whole of Ida::solve in one "
+                        "launch, step-size and order controller on the device with a pow that has glibc's bits); this is the whole pass "
+                        "with the lock-step host stepper instead (idaens_set_device_controller(0)): same work, same results"},
             "fast_vs_exact": {"fast_whole_pass_value": fast["iters"] / fast["seconds"], "unit": "Newton iters/s",
                               "systems": int(passes[0]["counts"].shape[1]), "systems_with_different_counts": differ,
                               "counts_compared": ["nst", "netf", "ncfn", "nni", "nsetups", "kused"],

@@ -6,8 +6,9 @@
  * toolchain exists in the build image, so the stand-in is C++ with the reference's structure (IdaNLProblem /
  * IdaLProblem / Newton state per system, same names, same error behaviour). All scalar control logic (set_coeffs,
  * lsetup decision, idaNlsConvTest incl. powf, test_error decisions, handle_n_flag, complete_step order/step selection,
- * stop tests, get_solution coefficients) runs on the host with the platform libm, per system, exactly as
- * src/lib.rs / src/impl_*.rs do; vectors never leave the device.
+ * stop tests, get_solution coefficients) is one source (rust-ida_amd/host/ida_controller.hpp) that runs on the host with the
+ * platform libm, per system, exactly as src/lib.rs / src/impl_*.rs do -- or, for small systems, on the device with a pow
+ * that reproduces that libm's bits (idaens_set_device_controller); vectors never leave the device.
  */
 #ifndef IDA_ENSEMBLE_H
 #define IDA_ENSEMBLE_H
@@ -49,11 +50,16 @@ const char* idaens_last_error(const idaens* e);
 
 /* optional inputs (the reference has defaults only, src/lib.rs:309-321; setters follow C IDA's names) */
 int idaens_set_max_num_steps(idaens* e, long mxstep); /* 0 = unlimited; default 500 (MXSTEP_DEFAULT) */
-int idaens_set_max_ord(idaens* e, int maxord);
+int idaens_set_max_ord(idaens* e, int maxord);          /* 1..5, default 5 */
 /* on (default; always off for IDAHIP_HOST_CALLBACK problems): a Newton solve runs its first two iterations and their
  * convergence tests in one device call (idahip_newton_iter2) instead of one host round trip per iteration. Results are
  * identical either way; the switch exists for measurements. */
-int idaens_set_fused_newton(idaens* e, int on);        /* 1..5, default 5 */
+int idaens_set_fused_newton(idaens* e, int on);
+/* on (default): for small systems with a device residual (n <= 8: Roberts, Lorenz63; IDA_NORMAL, no root functions, no trace)
+ * a solve / solve_schedule / stream call is ONE device launch in which every system runs its own time loop with the
+ * step-size and order controller on the device (idahip_tiny_solve); off: the lock-step host stepper for
+ * every problem. Same results either way (same controller source, pow with glibc's bits); the switch is the A/B. */
+int idaens_set_device_controller(idaens* e, int on);
 /* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
  * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call
  * before the first solve; idaens_solve then reports IDAENS_ROOT_RETURN with tret = the root, yy/yp = the solution there,

@@ -172,6 +172,36 @@ int idahip_get_dky(idahip_ctx* ctx, const int32_t* hKfirst, const int32_t* hKlas
 int idahip_snapshot_initial(idahip_ctx* ctx);
 int idahip_restore_initial(idahip_ctx* ctx, const int32_t* hIdx, int nsys);
 
+/* ---- device-resident stepper for small systems (n <= 8, IDAHIP_ROBERTS / IDAHIP_LORENZ63) ----
+ * The whole of Ida::solve (src/impl_solve.rs:69-376: first-call block, loop-top checks, Ida::step with its attempt loop,
+ * Newton::solve, error test, complete_step, stop tests and the interpolation to tout), for every system of the ctx, in ONE
+ * launch: one thread per IVP runs its own time loop, the step-size and order controller included. The
+ * controller is the same source as libidaens' host stepper (rust-ida_amd/host/ida_controller.hpp) compiled for the device
+ * with a pow that reproduces glibc's bits (rust-ida_amd/csrc/glibc_pow.hpp).
+ *   hSys       [batch] controller states (idactl::SysCore of ida_controller.hpp, sys_bytes = sizeof of it), in and out
+ *   call       the schedule and the limits of this call (what idaens_solve / _solve_schedule / _stream take)
+ *   hRoundsDone[batch] out: step-attempt rounds each system took part in
+ *   hAcc       [2] out: Newton iterations of the integrations retired by `recycle`, number of those integrations
+ *   hYout/hYPout optional raw dumps [ntout][batch][n] of the device-side output slots (a slot is written when its tout is
+ *              reached; the caller knows from the states which slots are new)
+ * idahip_pow_batch: the controller's pow for n argument pairs, computed on the device (test hook for glibc_pow.hpp). */
+typedef struct idahip_tiny_call {
+    const double* touts; /* [ntout] host */
+    int ntout;
+    int recycle;         /* idaens_stream: a system that finished its schedule is created anew and starts over */
+    int resume;          /* continuing a round-limited schedule call: idle systems have finished */
+    long max_rounds;     /* step attempts per system in this launch; 0 = until every system has returned */
+    long mxstep;
+    int maxord;
+    long maxnef, maxncf;
+    double epcon, hmax_inv, t0;
+    const int64_t* start_round; /* [batch] host or NULL: idaens_stream's staggered start (absolute round numbers) */
+    int64_t round_base;         /* rounds executed before this call */
+} idahip_tiny_call;
+int idahip_tiny_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
+                      double* hYout, double* hYPout);
+int idahip_pow_batch(idahip_ctx* ctx, const double* hX, const double* hY, double* hOut, size_t count);
+
 /* LU implementation choice. All variants factor in 64-column super-panels with a rank-64 trailing
  * update in wave-private 16-row strips and differ in how a super-panel is factored:
  *   4 = default, bit-identical to dense_get_rf: one wavefront per matrix factors the whole super-panel (<= 512 live rows);

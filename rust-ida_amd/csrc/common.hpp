@@ -65,6 +65,13 @@ struct idahip_ctx {
                          // 5: the same with FMA-contracted updates (`fast`, not bit-identical to the reference)
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
+    // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)
+    void* tiny_sys = nullptr;
+    double *tiny_touts = nullptr, *tiny_yout = nullptr, *tiny_ypout = nullptr;
+    int64_t *tiny_start = nullptr, *tiny_rounds = nullptr;
+    uint64_t* tiny_acc = nullptr;
+    int tiny_ntout_cap = 0, tiny_yout_cap = 0;
+
     // problem data
     double* params = nullptr;  // [batch][nparam]
     int nparam = 0;

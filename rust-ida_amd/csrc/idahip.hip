@@ -5,6 +5,7 @@
 #include "problem_kernels.hpp"
 #include "solve_kernels.hpp"
 #include "vector_kernels.hpp"
+#include "tiny_ida.hpp"
 
 using namespace idahip;
 
@@ -133,7 +134,8 @@ int idahip_destroy(idahip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
-                    c->ic_yp, c->dky, c->cb_stage};
+                    c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
+                    c->tiny_acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < NSLOT; ++i) {
@@ -918,6 +920,106 @@ int idahip_restore_initial(idahip_ctx* c, const int32_t* hIdx, int nsys) {
         if ((rc = post_launch(c, "restore_initial"))) return rc;
     }
     return ap.finish_async();
+}
+
+// ---------------------------------------------------------------------------------------------- device-resident stepper (n <= 8)
+__global__ void pow_batch_kernel(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = glibc_pow::pow(x[i], y[i]);
+}
+
+int idahip_pow_batch(idahip_ctx* c, const double* hX, const double* hY, double* hOut, size_t count) {
+    DevGuard dev_guard__(c);
+    if (!c) return -1;
+    if (!hX || !hY || !hOut) return fail(c, -2, "null argument");
+    if (count == 0) return 0;
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    int rc = dalloc(c, &dx, count);
+    if (!rc) rc = dalloc(c, &dy, count);
+    if (!rc) rc = dalloc(c, &dout, count);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(dx, hX, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dy, hY, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pow_batch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (const double*)dx,
+                               (const double*)dy, dout, count);
+            e = hipMemcpyAsync(hOut, dout, count * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, -100, "idahip_pow_batch: %s", hipGetErrorString(e));
+    }
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
+                      double* hYout, double* hYPout) {
+    DevGuard dev_guard__(c);
+    if (!c) return -1;
+    if (!hSys || !call || !hRoundsDone || !hAcc || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
+    if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
+    if (c->n > TINY_N || (c->kind != IDAHIP_ROBERTS && c->kind != IDAHIP_LORENZ63))
+        return fail(c, -2, "the device-resident stepper takes the Roberts and Lorenz63 problems (n <= %d)", TINY_N);
+    if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
+    if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
+    const int batch = c->batch, n = c->n;
+    int rc = 0;
+    if (!c->tiny_sys) {
+        IDAHIP_HIP(c, hipMalloc(&c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore)));
+        rc |= dalloc(c, &c->tiny_start, (size_t)batch);
+        rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
+        rc |= dalloc(c, &c->tiny_acc, (size_t)2);
+        if (rc) return rc;
+    }
+    if (call->ntout > c->tiny_ntout_cap) {
+        if (c->tiny_touts) (void)hipFree(c->tiny_touts);
+        if ((rc = dalloc(c, &c->tiny_touts, (size_t)call->ntout))) return rc;
+        c->tiny_ntout_cap = call->ntout;
+    }
+    const size_t ysz = (size_t)call->ntout * batch * n;
+    if ((hYout || hYPout) && call->ntout > c->tiny_yout_cap) {
+        if (c->tiny_yout) (void)hipFree(c->tiny_yout);
+        if (c->tiny_ypout) (void)hipFree(c->tiny_ypout);
+        c->tiny_yout = c->tiny_ypout = nullptr;
+        if ((rc = dalloc(c, &c->tiny_yout, ysz))) return rc;
+        if ((rc = dalloc(c, &c->tiny_ypout, ysz))) return rc;
+        c->tiny_yout_cap = call->ntout;
+    }
+    IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_sys, hSys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyHostToDevice, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_touts, call->touts, sizeof(double) * call->ntout, hipMemcpyHostToDevice, c->stream));
+    if (call->start_round)
+        IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_start, call->start_round, sizeof(int64_t) * batch, hipMemcpyHostToDevice, c->stream));
+    IDAHIP_HIP(c, hipMemsetAsync(c->tiny_acc, 0, 2 * sizeof(uint64_t), c->stream));
+    TinyIdaArgs a;
+    a.sys = (idactl::SysCore*)c->tiny_sys;
+    a.v = vec_state(c);
+    a.savres = c->savres; a.lu = c->lu; a.piv = (long long*)c->piv; a.params = c->params; a.nparam = c->nparam;
+    a.ic_y = c->ic_y; a.ic_yp = c->ic_yp;
+    a.touts = c->tiny_touts; a.ntout = call->ntout; a.recycle = call->recycle; a.resume = call->resume;
+    a.max_rounds = call->max_rounds; a.mxstep = call->mxstep; a.maxord = call->maxord; a.maxnef = call->maxnef; a.maxncf = call->maxncf;
+    a.epcon = call->epcon; a.hmax_inv = call->hmax_inv; a.t0 = call->t0;
+    a.start_round = call->start_round ? (const long long*)c->tiny_start : nullptr;
+    a.round_base = call->round_base;
+    a.yout = hYout ? c->tiny_yout : nullptr;
+    a.ypout = hYPout ? c->tiny_ypout : nullptr;
+    a.rounds_done = (long long*)c->tiny_rounds;
+    a.acc = (unsigned long long*)c->tiny_acc;
+    a.batch = batch;
+    {
+        KTimer kt(c, IDAHIP_K_VECTOR, batch);
+        if (c->kind == IDAHIP_ROBERTS) hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_ROBERTS>, dim3((batch + 63) / 64), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_LORENZ63>, dim3((batch + 63) / 64), dim3(64), 0, c->stream, a);
+        if ((rc = post_launch(c, "tiny_ida"))) return rc;
+    }
+    IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(hRoundsDone, c->tiny_rounds, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(hAcc, c->tiny_acc, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (hYout) IDAHIP_HIP(c, hipMemcpyAsync(hYout, c->tiny_yout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));
+    if (hYPout) IDAHIP_HIP(c, hipMemcpyAsync(hYPout, c->tiny_ypout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {

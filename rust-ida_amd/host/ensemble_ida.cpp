@@ -41,60 +41,16 @@
 
 #include "../../include/ida_ensemble.h"
 
+#include "ida_controller.hpp"
+
 namespace {
 
-constexpr int MXORDP1 = 6;
-constexpr int MAXORD_DEFAULT = 5;
-constexpr long MXSTEP_DEFAULT = 500;
-constexpr int MXNCF = 10, MXNEF = 10;
-constexpr double EPCON = 0.33;
-constexpr double XRATE = 0.25;
-constexpr int MAXNLSIT = 4;
-constexpr double RATEMAX = 0.9;
+using namespace idactl;  // constants, SysCore and the scalar controller shared with the device-resident stepper
 
-enum NlsCode { NLS_SUCCESS = 0, NLS_CONV_RECVR = 1, NLS_LSETUP_RECVR = 2 };
-enum NFlag { NFLAG_NONE = 0, NFLAG_TEST_FAIL = 1, NFLAG_CONV_RECVR = 2, NFLAG_LSETUP_RECVR = 3 };
-enum Phase { PH_IDLE = 0 /* between solve calls */, PH_LOOP_TOP = 1 /* needs the loop-top checks, then a new step */,
-             PH_RETRY = 2 /* inside step()'s attempt loop */ };
-
-struct Sys {
-    // --- Ida scalars (src/lib.rs:89-244)
-    double psi[MXORDP1] = {0}, alpha[MXORDP1] = {0}, beta[MXORDP1] = {0}, sigma[MXORDP1] = {0}, gamma[MXORDP1] = {0};
-    double cvals[MXORDP1] = {0}, dvals[MAXORD_DEFAULT] = {0};
-    int kk = 0, kused = 0, knew = 0, phase = 0, ns = 0;
-    double hin = 0.0, h0u = 0.0, hh = 0.0, hused = 0.0, rr = 0.0;
-    double tretlast = 0.0, cjlast = 0.0, eps_newt = 0.0, tolsf = 1.0;
-    double tn = 0.0;
-    long nst = 0, ncfn = 0, netf = 0;
-    bool setup_done = false;
-    // --- IdaNLProblem / IdaLProblem scalars (src/ida_nls.rs:27-59, src/ida_ls.rs:84-105)
-    double cj = 0.0, cjold = 0.0, cjratio = 0.0, ss = 0.0, oldnrm = 0.0, toldel = 0.0;
-    long nre = 0, nsetups = 0, nje = 0;
-    // --- Newton (crates/nonlinear/src/newton.rs:14-32)
-    bool jcur = false;
-    int curiter = 0;
-    long niters = 0, nconvfails = 0;
-    // --- lock-step bookkeeping
-    int ph = PH_IDLE;
-    double saved_t = 0.0, ck = 0.0;
-    long ncf = 0, nef = 0, nstloc = 0;
-    bool call_lsetup = false;
-    int nls_ret = 0;
-    double phi0nrm = 0.0;  // ||phi[0]||_wrms(ewt) for the next step's tolsf test
-    bool ewt_bad = false;
-    long n_attempts = 0;
-    int status = 0;
-    double tret = 0.0;
-    bool dead = false;  // a fatal IdaError was returned: later solve calls report it again
-    double tout_cur = 0.0;  // the tout of the Ida::solve call this system is inside
-    int sched_i = 0;        // index of that tout in the caller's schedule (idaens_solve: always 0)
+struct Sys : SysCore {
     // --- root finding (src/lib.rs:225-244, src/impl_r_check.rs); the vectors have nrtfn entries when roots are enabled
     std::vector<double> glo, ghi, grout, iroots;
     std::vector<uint8_t> gactive;
-    bool irfnd = false;
-    double tlo = 0.0, thi = 0.0, trout = 0.0, ttol = 0.0, toutc = 0.0;
-    int taskc = 0;
-    long nge = 0;
 };
 
 }  // namespace
@@ -115,6 +71,7 @@ struct idaens {
     double t0 = 0.0;                // every system starts at tn = t0 (Sys default)
     int64_t retired_iters = 0, passes = 0;  // idaens_stream: Newton iterations / integrations of systems already restarted
     bool have_ic = false, streaming = false;
+    bool device_ctl = true;    // small device problems: the whole of Ida::solve in one launch (idahip_tiny_solve), no lock-step rounds
     bool fused_newton = true;  // first two Newton iterations and their convergence tests in one device call (idahip_newton_iter2)
     std::vector<int64_t> start_round;  // idaens_stream with a stagger: the round at which each system first enters
     // root functions g_i(t, y, y') = y[rt_comp[i]] - rt_thr[i] (the form of the reference's Roberts example,
@@ -156,209 +113,6 @@ static double prof_now() {
         if (g_prof) g_prof_dev += prof_now() - t0__;                                                        \
         if (rc__ < 0) return efail((e), rc__, "%s failed (%d): %s", #call, rc__, idahip_last_error((e)->ctx)); \
     } while (0)
-
-double signum(double x) {  // f64::signum
-    if (std::isnan(x)) return x;
-    return std::signbit(x) ? -1.0 : 1.0;
-}
-
-// ---------------------------------------------------------------- set_coeffs scalars (lib.rs:722-766); returns ck
-double set_coeffs(Sys& s) {
-    if (s.hh != s.hused || s.kk != s.kused) s.ns = 0;
-    s.ns = std::min(s.ns + 1, s.kused + 2);
-    if (s.kk + 1 >= s.ns) {
-        s.beta[0] = 1.0;
-        s.alpha[0] = 1.0;
-        double temp1 = s.hh;
-        s.gamma[0] = 0.0;
-        s.sigma[0] = 1.0;
-        for (int i = 1; i <= s.kk; ++i) {
-            const double scalar_i = (double)i;
-            const double temp2 = s.psi[i - 1];
-            s.psi[i - 1] = temp1;
-            s.beta[i] = s.beta[i - 1] * s.psi[i - 1] / temp2;
-            temp1 = temp2 + s.hh;
-            s.alpha[i] = s.hh / temp1;
-            s.sigma[i] = scalar_i * s.sigma[i - 1] * s.alpha[i];
-            s.gamma[i] = s.gamma[i - 1] + s.alpha[i - 1] / s.hh;
-        }
-        s.psi[s.kk] = temp1;
-    }
-    double alphas = 0.0, alpha0 = 0.0;
-    for (int i = 0; i < s.kk; ++i) {
-        const double scalar_i = (double)(i + 1);
-        alphas -= 1.0 / scalar_i;
-        alpha0 -= s.alpha[i];
-    }
-    s.cjlast = s.cj;
-    s.cj = -alphas / s.hh;
-    double ck = std::fabs(s.alpha[s.kk] + alphas - alpha0);
-    ck = std::fmax(ck, s.alpha[s.kk]);
-    return ck;  // the phi-star scaling phi[j] *= beta[j], j = ns..kk, is done by idahip_predict
-}
-
-// ---------------------------------------------------------------- test_error decisions (lib.rs:967-1039)
-bool test_error(Sys& s, double ck, const double* nrm /* enorm_k, enorm_km1, enorm_km2 */, double* err_k_out, double* err_km1_out) {
-    const double scalar_kk = (double)s.kk;
-    const double enorm_k = nrm[0];
-    const double err_k = s.sigma[s.kk] * enorm_k;
-    const double terr_k = err_k * (scalar_kk + 1.0);
-    double err_km1 = 0.0;
-    int knew = s.kk;
-    if (s.kk > 1) {
-        const double enorm_km1 = nrm[1];
-        err_km1 = s.sigma[s.kk - 1] * enorm_km1;
-        const double terr_km1 = scalar_kk * err_km1;
-        if (s.kk > 2) {
-            const double enorm_km2 = nrm[2];
-            const double err_km2 = s.sigma[s.kk - 2] * enorm_km2;
-            const double terr_km2 = (scalar_kk - 1.0) * err_km2;
-            if (std::fmax(terr_km1, terr_km2) <= terr_k) knew = s.kk - 1;
-        } else {
-            if (terr_km1 <= terr_k * 0.5) knew = s.kk - 1;
-        }
-    }
-    s.knew = knew;
-    *err_k_out = err_k;
-    *err_km1_out = err_km1;
-    return (ck * enorm_k) <= 1.0;
-}
-
-// ---------------------------------------------------------------- restore scalars (lib.rs:1044-1083)
-void restore_scalars(Sys& s) {
-    s.tn = s.saved_t;
-    for (int j = 1; j < s.kk + 1; ++j) s.psi[j - 1] = s.psi[j] - s.hh;
-    if (s.ns <= s.kk) {
-        for (int j = s.ns; j <= s.kk; ++j) s.cvals[j - s.ns] = 1.0 / s.beta[j];
-    }
-}
-
-// ---------------------------------------------------------------- handle_n_flag (lib.rs:1120-1244); 0 = predict again
-int handle_n_flag(idaens* e, Sys& s, int nflag, double err_k, double err_km1) {
-    s.phase = 1;
-    if (nflag == NFLAG_TEST_FAIL) {
-        s.nef += 1;
-        s.netf += 1;
-        if (s.nef == 1) {
-            const double err_knew = (s.kk == s.knew) ? err_k : err_km1;
-            s.kk = s.knew;
-            {
-                const double base = 2.0 * err_knew + 0.0001;
-                const double arg = 1.0 / (double)(s.kk + 1);
-                s.rr = 0.9 * std::pow(base, -arg);
-            }
-            s.rr = std::fmax(0.25, std::fmin(0.9, s.rr));
-            s.hh *= s.rr;
-            return 0;
-        } else if (s.nef == 2) {
-            s.kk = s.knew;
-            s.rr = 0.25;
-            s.hh *= s.rr;
-            return 0;
-        } else if (s.nef < e->maxnef) {
-            s.kk = 1;
-            s.rr = 0.25;
-            s.hh *= s.rr;
-            return 0;
-        }
-        return IDAENS_ERR_FAIL;
-    }
-    s.ncf += 1;
-    s.ncfn += 1;
-    s.rr = 0.25;
-    s.hh *= s.rr;
-    if (s.ncf < e->maxncf) return 0;
-    return IDAENS_CONV_FAIL;
-}
-
-// ---------------------------------------------------------------- complete_step scalars (impl_complete_step.rs:22-147)
-void complete_step_scalars(idaens* e, Sys& s, double err_k, double err_km1, double enorm_kp1) {
-    s.nst += 1;
-    const int kdiff = s.kk - s.kused;
-    s.kused = s.kk;
-    s.hused = s.hh;
-    if (s.knew == s.kk - 1 || s.kk == e->maxord) s.phase = 1;
-    if (s.phase == 0) {
-        if (s.nst > 1) {
-            s.kk += 1;
-            double hnew = 2.0 * s.hh;
-            const double tmp = std::fabs(hnew) * e->hmax_inv;
-            if (tmp > 1.0) hnew /= tmp;
-            s.hh = hnew;
-        }
-    } else {
-        enum { LOWER, MAINTAIN, RAISE } action;
-        double err_kp1 = 0.0;
-        if (s.knew == s.kk - 1) {
-            action = LOWER;
-        } else if (s.kk == e->maxord) {
-            action = MAINTAIN;
-        } else if (s.kk + 1 >= s.ns || kdiff == 1) {
-            action = MAINTAIN;
-        } else {
-            const double enorm = enorm_kp1;  // ||ee - phi[kk+1]||
-            err_kp1 = enorm / (double)(s.kk + 2);
-            const double terr_k = (double)(s.kk + 1) * err_k;
-            const double terr_kp1 = (double)(s.kk + 2) * err_kp1;
-            if (s.kk == 1) {
-                action = (terr_kp1 >= 0.5 * terr_k) ? MAINTAIN : RAISE;
-            } else {
-                const double terr_km1 = (double)s.kk * err_km1;
-                if (terr_km1 <= std::fmin(terr_k, terr_kp1)) action = LOWER;
-                else if (terr_kp1 >= terr_k) action = MAINTAIN;
-                else action = RAISE;
-            }
-        }
-        double err_knew;
-        if (action == RAISE) {
-            s.kk += 1;
-            err_knew = err_kp1;
-        } else if (action == LOWER) {
-            s.kk -= 1;
-            err_knew = err_km1;
-        } else {
-            err_knew = err_k;
-        }
-        double hnew = s.hh;
-        {
-            const double base = 2.0 * err_knew + 0.0001;
-            const double arg = -(1.0 / (double)(s.kk + 1));
-            s.rr = std::pow(base, arg);
-        }
-        if (s.rr >= 2.0) {
-            hnew = 2.0 * s.hh;
-            const double tmp = std::fabs(hnew) * e->hmax_inv;
-            if (tmp > 1.0) hnew /= tmp;
-        } else if (s.rr <= 1.0) {
-            s.rr = std::fmax(0.5, std::fmin(s.rr, 0.9));
-            hnew = s.hh * s.rr;
-        }
-        s.hh = hnew;
-    }
-}
-
-// ---------------------------------------------------------------- get_solution coefficients (lib.rs:1274-1317)
-// returns 0 and fills kord/cvals/dvals, or IDAENS_BAD_T
-int get_solution_coeffs(Sys& s, double t, int* kord_out) {
-    const double eps = std::numeric_limits<double>::epsilon();
-    const double tfuzz = 100.0 * eps * (std::fabs(s.tn) + std::fabs(s.hh)) * signum(s.hh);
-    const double tp = s.tn - s.hused - tfuzz;
-    if ((t - tp) * s.hh < 0.0) return IDAENS_BAD_T;
-    const int kord = (s.kused == 0) ? 1 : s.kused;
-    const double delt = t - s.tn;
-    double c = 1.0, d = 0.0;
-    double gam = delt / s.psi[0];
-    s.cvals[0] = c;
-    for (int j = 1; j <= kord; ++j) {
-        d = d * gam + c / s.psi[j - 1];
-        c = c * gam;
-        gam = (delt + s.psi[j - 1]) / s.psi[j];
-        s.cvals[j] = c;
-        s.dvals[j - 1] = d;
-    }
-    *kord_out = kord;
-    return 0;
-}
 
 struct SolList {  // systems whose yy/yp must be interpolated by the device
     std::vector<int32_t> idx, kord;
@@ -676,13 +430,7 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
                 ENS_CALL(e, idahip_nls_sys_setup(e->ctx, tn.data(), cj.data(), 1, info.data(), L.data(), (int)L.size()));
                 for (size_t q = 0; q < L.size(); ++q) {
                     Sys& s = S[L[q]];
-                    s.nsetups += 1;  // idaNlsLSetup (ida_nls.rs:168)
-                    s.nje += 1;      // idaLsSetup   (ida_ls.rs:250)
-                    s.jcur = true;
-                    s.cjold = s.cj;  // ida_nls.rs:177-179
-                    s.cjratio = 1.0;
-                    s.ss = 20.0;
-                    s.nls_ret = info[q] ? NLS_LSETUP_RECVR : NLS_SUCCESS;
+                    after_lsetup(s, info[q]);  // idaNlsLSetup / idaLsSetup bookkeeping (ida_nls.rs:168-179, ida_ls.rs:250)
                 }
             }
             for (int b : R) {
@@ -769,22 +517,8 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
             const int b = I[q];
             Sys& s = S[b];
             s.niters += 1;
-            // idaNlsConvTest (ida_nls.rs:218-266)
-            const double delnrm = nrm[q];
-            const int m = s.curiter;
             bool converged = false;
-            int ret = NLS_SUCCESS;
-            if (m == 0) {
-                s.oldnrm = delnrm;
-                if (delnrm <= 0.0001 * s.toldel) converged = true;
-            } else {
-                const double base = delnrm / s.oldnrm;
-                const double arg = 1.0 / (double)m;
-                const double rate = std::pow(base, arg);
-                if (rate > RATEMAX) ret = NLS_CONV_RECVR;
-                else s.ss = rate / (1.0 - rate);
-            }
-            if (ret == NLS_SUCCESS && !converged && s.ss * delnrm <= s.eps_newt) converged = true;
+            const int ret = conv_test(s, nrm[q], &converged);  // idaNlsConvTest (ida_nls.rs:218-266)
             after_ctest(b, ret, converged);
         }
         }
@@ -843,43 +577,13 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, SolveCall& C) {
     std::vector<double> beta(MXORDP1 * (size_t)na), gamma(MXORDP1 * (size_t)na);
     for (int q = 0; q < na; ++q) {
         Sys& s = S[act[q]];
-        if (s.ph == PH_LOOP_TOP) {  // entering step()
-            s.saved_t = s.tn;
-            if (s.nst == 0) {
-                s.kk = 1;
-                s.kused = 0;
-                s.hused = 0.0;
-                s.psi[0] = s.hh;
-                s.cj = 1.0 / s.hh;
-                s.phase = 0;
-                s.ns = 0;
-            }
-            s.ncf = 0;
-            s.nef = 0;
-            s.ph = PH_RETRY;
-        }
-        s.n_attempts += 1;
-        s.ck = set_coeffs(s);
-        s.tn += s.hh;
+        begin_attempt(s);  // step() prologue, set_coeffs, tn += hh, lsetup decision (ida_controller.hpp)
         kkns[2 * q] = s.kk;
         kkns[2 * q + 1] = s.ns;
         for (int j = 0; j < MXORDP1; ++j) {
             beta[MXORDP1 * q + j] = s.beta[j];
             gamma[MXORDP1 * q + j] = s.gamma[j];
         }
-        // nonlinear_solve prologue (lib.rs:792-812)
-        s.call_lsetup = false;
-        if (s.nst == 0) {
-            s.cjold = s.cj;
-            s.ss = 20.0;
-            s.call_lsetup = true;
-        }
-        s.cjratio = s.cj / s.cjold;
-        const double temp1 = (1.0 - XRATE) / (1.0 + XRATE);
-        const double temp2 = 1.0 / temp1;
-        if (s.cjratio < temp1 || s.cjratio > temp2) s.call_lsetup = true;
-        if (s.cj != s.cjlast) s.ss = 100.0;
-        s.nls_ret = NLS_SUCCESS;
     }
     ENS_CALL(e, idahip_predict(e->ctx, kkns.data(), beta.data(), gamma.data(), act.data(), na));
 
@@ -922,7 +626,7 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, SolveCall& C) {
                 rest_kkns.push_back(ns_att);
                 rest_cvals.insert(rest_cvals.end(), s.cvals, s.cvals + MXORDP1);
             }
-            const int kflag = handle_n_flag(e, s, nflag, err_k, err_km1);
+            const int kflag = handle_n_flag(s, nflag, err_k, err_km1, e->maxnef, e->maxncf);
             if (kflag != 0) {  // step failed for good: Ida::solve's failed-step path (impl_solve.rs:300-313)
                 if (queue_solution(s, b, s.tn, sl) == 0) {
                     s.tret = s.tn;
@@ -942,7 +646,7 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, SolveCall& C) {
             continue;
         }
         // accepted: complete_step (scalars now, vectors below), ee *= ck
-        complete_step_scalars(e, s, err_k, err_km1, norms[4 * q + 3]);
+        complete_step_scalars(s, err_k, err_km1, norms[4 * q + 3], e->maxord, e->hmax_inv);
         done_idx.push_back(b);
         done_kused.push_back(s.kused);
         done_ck.push_back(s.ck);
@@ -1044,6 +748,11 @@ int idaens_set_max_num_steps(idaens* e, long mxstep) {
     e->mxstep = mxstep;
     return 0;
 }
+int idaens_set_device_controller(idaens* e, int on) {
+    if (!e) return -1;
+    e->device_ctl = on != 0;
+    return 0;
+}
 int idaens_set_fused_newton(idaens* e, int on) {
     if (!e) return -1;
     e->fused_newton = on != 0 && idahip_kind(e->ctx) != IDAHIP_HOST_CALLBACK;
@@ -1141,7 +850,79 @@ int continue_schedule(idaens* e, SolveCall& C, int b) {
     }
 }
 
+// Small systems with a device residual: the whole call runs on the device, one thread per IVP with its own time loop and the
+// controller of ida_controller.hpp compiled for the device (idahip_tiny_solve). The host only moves the controller states.
+bool device_ctl_applies(const idaens* e, const SolveCall& C) {
+    const int k = idahip_kind(e->ctx);
+    return e->device_ctl && e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63) && e->nrtfn == 0 && C.itask == IDAENS_NORMAL &&
+           e->trace_sys < 0;
+}
+
+int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds) {
+    std::vector<Sys>& S = e->sys;
+    const int batch = e->batch;
+    const size_t n = e->n;
+    const bool resume = C.ntout > 1 && e->sched_unfinished;
+    auto reached_of = [&](const Sys& s) { return s.sched_i + ((s.ph == PH_IDLE && s.status == IDAENS_SUCCESS) ? 1 : 0); };
+    std::vector<SysCore> st(batch);
+    std::vector<int> prev(batch, 0);
+    for (int b = 0; b < batch; ++b) {
+        st[b] = S[b];
+        if (resume) prev[b] = reached_of(S[b]);
+    }
+    idahip_tiny_call call;
+    call.touts = C.touts;
+    call.ntout = C.ntout;
+    call.recycle = C.recycle ? 1 : 0;
+    call.resume = resume ? 1 : 0;
+    call.max_rounds = max_rounds;
+    call.mxstep = e->mxstep;
+    call.maxord = e->maxord;
+    call.maxnef = e->maxnef;
+    call.maxncf = e->maxncf;
+    call.epcon = e->epcon;
+    call.hmax_inv = e->hmax_inv;
+    call.t0 = e->t0;
+    call.start_round = (C.recycle && !e->start_round.empty()) ? e->start_round.data() : nullptr;
+    call.round_base = e->total_rounds;
+    std::vector<int64_t> rounds(batch, 0);
+    uint64_t acc[2] = {0, 0};
+    std::vector<double> yo, ypo;
+    if (C.hYout) yo.resize((size_t)C.ntout * batch * n);
+    if (C.hYPout) ypo.resize((size_t)C.ntout * batch * n);
+    ENS_CALL(e, idahip_tiny_solve(e->ctx, st.data(), sizeof(SysCore), &call, rounds.data(), acc, C.hYout ? yo.data() : nullptr,
+                                  C.hYPout ? ypo.data() : nullptr));
+    int64_t rmax = 0;
+    bool unfinished = false;
+    for (int b = 0; b < batch; ++b) {
+        static_cast<SysCore&>(S[b]) = st[b];
+        rmax = std::max(rmax, rounds[b]);
+        Sys& s = S[b];
+        const int now = reached_of(s);
+        for (int i = prev[b]; i < now; ++i) {  // the outputs of the touts reached in this call
+            const size_t off = ((size_t)i * batch + b) * n;
+            if (C.hYout) std::memcpy(C.hYout + off, yo.data() + off, sizeof(double) * n);
+            if (C.hYPout) std::memcpy(C.hYPout + off, ypo.data() + off, sizeof(double) * n);
+        }
+        if (C.hReached) C.hReached[b] = now;
+        if (s.ph != PH_IDLE) {
+            hStatus[b] = IDAENS_UNFINISHED;
+            hTret[b] = s.tn;
+            unfinished = true;
+        } else {
+            hStatus[b] = s.status;
+            hTret[b] = s.tret;
+        }
+    }
+    e->total_rounds += rmax;
+    e->retired_iters += (int64_t)acc[0];
+    e->passes += (int64_t)acc[1];
+    e->sched_unfinished = C.ntout > 1 && unfinished;
+    return 0;
+}
+
 int solve_core(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds) {
+    if (device_ctl_applies(e, C)) return solve_core_device(e, C, hTret, hStatus, max_rounds);
     const double eps = std::numeric_limits<double>::epsilon();
     std::vector<Sys>& S = e->sys;
     SolList& sl = C.sl;

@@ -35,10 +35,11 @@ HIP_SYMBOLS = [
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_newton_iter2", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
+    "idahip_tiny_solve", "idahip_pow_batch",
     "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [
-    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_roots",
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots",
     "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
@@ -105,6 +106,8 @@ def load():
     H.idahip_get_solution.argtypes = [vp, i32p, dp, dp, i32p, ci]
     H.idahip_get_dky.argtypes = [vp, i32p, i32p, dp, dp, i32p, ci]
     H.idahip_set_lu_variant.argtypes = [vp, ci]
+    H.idahip_pow_batch.argtypes = [vp, dp, dp, dp, C.c_size_t]
+    H.idahip_newton_iter2.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp, i32p, i32p, ci]
     H.idahip_set_host_problem.argtypes = [vp, RES_FN, JAC_FN, vp]
     H.idahip_timing_enable.argtypes = [vp, ci]
     H.idahip_timing_get.argtypes = [vp, ci, dp, i64p, i64p]
@@ -115,6 +118,8 @@ def load():
     E.idaens_last_error.restype = C.c_char_p
     E.idaens_set_max_num_steps.argtypes = [vp, C.c_long]
     E.idaens_set_max_ord.argtypes = [vp, ci]
+    E.idaens_set_fused_newton.argtypes = [vp, ci]
+    E.idaens_set_device_controller.argtypes = [vp, ci]
     E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
     E.idaens_get_roots.argtypes = [vp, i32p]
     E.idaens_solve.argtypes = [vp, cd, ci, dp, i32p, C.c_long]
@@ -354,6 +359,13 @@ class Ctx:
         dvals = _f64(np.broadcast_to(dvals, (idx.size, 5)))
         self._chk(self.H.idahip_get_solution(self.h, _p(kord, i32p), _p(cvals), _p(dvals), _p(idx, i32p), idx.size), "get_solution")
 
+    def pow_batch(self, x, y):
+        """The device controller's pow (glibc_pow.hpp) for arrays of arguments."""
+        x, y = _f64(x), _f64(y)
+        out = np.empty_like(x)
+        self._chk(self.H.idahip_pow_batch(self.h, _p(x), _p(y), _p(out), x.size), "pow_batch")
+        return out
+
     def set_lu_variant(self, variant):
         self._chk(self.H.idahip_set_lu_variant(self.h, int(variant)), "set_lu_variant")
 
@@ -422,6 +434,10 @@ class Ensemble:
 
     def set_fused_newton(self, on):
         self.E.idaens_set_fused_newton(self.h, int(on))
+
+    def set_device_controller(self, on):
+        """Small device problems: the whole of Ida::solve in one launch (default on) or the lock-step host stepper."""
+        self.E.idaens_set_device_controller(self.h, int(on))
 
     def set_max_ord(self, maxord):
         if self.E.idaens_set_max_ord(self.h, int(maxord)) != 0:

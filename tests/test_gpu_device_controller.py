@@ -1,0 +1,125 @@
+"""The device-resident stepper for small systems (idahip_tiny_solve: the whole of Ida::solve in one launch, step-size and
+order controller on the device) against the lock-step host stepper (same controller source, platform pow)
+and against the CPU oracle. Bar: bit-identical states, step sizes, orders and counters."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_ensemble import CNT, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make(prob, device_ctl):
+    import idahip
+    from idahip import problems
+    ctx = problems.make_ctx(prob)
+    ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
+    ens.set_device_controller(device_ctl)
+    return ctx, ens
+
+
+def state(ens):
+    c = ens.counters()
+    return {**{k: c[k] for k in CNT + ("kused", "kk", "nls_nconvfails")}, "hused": ens.real("hused"), "hh": ens.real("hh"), "tn": ens.real("tn"),
+            "yy": ens.yy(), "yp": ens.yp()}
+
+
+def same(a, b):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def roberts_batch(batch=8):
+    from idahip import problems
+    p = problems.roberts()
+    rng = np.random.Generator(np.random.PCG64(5))
+    y0 = np.tile(p["yy0"], (batch, 1))
+    y0[1:, 0] -= 1e-3 * rng.uniform(0, 1, batch - 1)   # consistent perturbation: y1 + y2 + y3 = 1 kept
+    y0[1:, 2] = 1.0 - y0[1:, 0] - y0[1:, 1]
+    yp0 = np.stack([-0.04 * y0[:, 0] + 1e4 * y0[:, 1] * y0[:, 2], 0.04 * y0[:, 0] - 1e4 * y0[:, 1] * y0[:, 2] - 3e7 * y0[:, 1] ** 2,
+                    np.zeros(batch)], axis=1)
+    yp0[:, 2] = -(yp0[:, 0] + yp0[:, 1])
+    p.update(yy0=y0, yp0=yp0)
+    return p
+
+
+@pytest.mark.parametrize("name", ["lorenz63", "roberts"])
+def test_device_stepper_equals_host_stepper_and_oracle(name):
+    """Call by call (Ida::solve(tout) for every output time): device-resident stepper == host stepper == oracle."""
+    from idahip import problems
+    prob = problems.lorenz63(batch=192) if name == "lorenz63" else roberts_batch()
+    touts = prob["touts"][:20] if name == "lorenz63" else prob["touts"]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    ref = run_oracle(prob, touts)
+    for i, t in enumerate(touts):
+        sd, td = dev.solve(t)
+        sh, th = host.solve(t)
+        assert (sd == 0).all() and np.array_equal(sd, sh) and np.array_equal(td, th)
+        same(state(dev), state(host))
+        assert np.array_equal(dev.yy(), ref["yy"][i]) and np.array_equal(dev.yp(), ref["yp"][i])
+    c = dev.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(c["kused"], ref["kused"]) and np.array_equal(dev.real("hused"), ref["hused"])
+    assert dev.total_rounds() == host.total_rounds()
+    if name == "roberts":  # the reference's own run is system 0
+        assert (c["nst"][0], c["n_attempts"][0], c["nni"][0], c["nsetups"][0], c["netf"][0]) == (362, 377, 537, 60, 15)
+
+
+def test_schedule_outputs_and_round_limited_resume():
+    """idaens_solve_schedule on the device: outputs at every tout, and a call cut into slices of 37 rounds gives the same."""
+    from idahip import problems
+    prob = problems.lorenz63(batch=96)
+    touts = prob["touts"]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    sd, td, rd, yd, ypd = dev.solve_schedule(touts, outputs=True)
+    sh, th, rh, yh, yph = host.solve_schedule(touts, outputs=True)
+    assert (sd == 0).all() and np.array_equal(rd, rh) and (rd == len(touts)).all()
+    assert np.array_equal(yd, yh) and np.array_equal(ypd, yph)
+    same(state(dev), state(host))
+    assert dev.total_rounds() == host.total_rounds()
+    cs, sl = make(prob, 1)
+    ys = np.full_like(yd, np.nan)
+    for _ in range(1000):
+        s, t, r, yo, ypo = sl.solve_schedule(touts, max_rounds=37, outputs=True)
+        m = ~np.isnan(yo)
+        ys[m] = yo[m]
+        if (s != 99).all():
+            break
+    assert (s == 0).all() and np.array_equal(ys, yd)
+    same(state(sl), state(dev))
+
+
+def test_stream_mode_on_the_device():
+    """idaens_stream (finished systems restart at once, staggered first starts): same totals and states as the host stepper."""
+    from idahip import problems
+    prob = problems.lorenz63(batch=64)
+    touts = prob["touts"][:10]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    for k, stag in ((150, 40), (1, 0), (1, 0), (77, 0)):
+        pd = dev.stream(touts, k, stagger_rounds=stag)
+        ph = host.stream(touts, k, stagger_rounds=stag)
+        assert pd == ph
+        assert dev.total_rounds() == host.total_rounds() and dev.total_newton_iters() == host.total_newton_iters()
+        same(state(dev), state(host))
+    assert pd > 0
+
+
+def test_failures_are_reported_like_the_host_stepper():
+    """mxstep exhausted (recoverable TOO_MUCH_WORK, the next call continues) on both steppers."""
+    from idahip import problems
+    prob = problems.lorenz63(batch=16)
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    for e in (dev, host):
+        e.set_max_num_steps(25)
+    for _ in range(4):
+        sd, td = dev.solve(2.0)
+        sh, th = host.solve(2.0)
+        assert np.array_equal(sd, sh) and np.array_equal(td, th)
+        same(state(dev), state(host))
+    assert (sd == -1).any() or (sd == 0).all()
