@@ -7,6 +7,14 @@
 //!   system taking exactly the steps the reference's `Ida::solve` takes for it (same step sizes, orders, counters, bits).
 //! * [`HostProblem`] carries any `IdaProblem`-style residual / Jacobian pair (src/traits.rs:12-70) across the C ABI as
 //!   host callbacks (problem kind `IDAHIP_HOST_CALLBACK`); the four built-in device problems are selected by [`Problem`].
+//! * [`nls::HipNlsProblem`] implements `nonlinear::NLProblem<f64, D>` (crates/nonlinear/src/traits.rs:5-127) on the
+//!   ctx-resident `IdaNLProblem` state at batch = 1, [`nls::HipNewton`] implements `nonlinear::NLSolver<f64, D>`
+//!   (traits.rs:129-209) -- the call shapes of src/lib.rs:819,833-840 -- and, with the cargo feature `ida-problem`,
+//!   [`problem::IdaProblemAdapter`] turns any `ida::traits::IdaProblem` (src/traits.rs:12-94) into a [`HostProblem`].
+//!
+//! STATUS: experimental, never compiled. The build image of this repository has no Rust toolchain; the crate is checked only
+//! lexically and against the C ABI (tests/test_rust_bindings.py: every `sys::` item exists in the generated bindings, which
+//! match the headers and the exported symbols). Expect trait-bound and lifetime fixes at the first `cargo check`.
 //!
 //! Errors follow the reference: `linear::Error::LUFactFail { col }` with the 1-based column (dense.rs:121) for a zero pivot;
 //! anything else the library reports (< 0: bad argument, HIP failure) is a programming or environment error and surfaces
@@ -17,6 +25,10 @@ use std::marker::PhantomData;
 use std::os::raw::{c_double, c_int, c_void};
 use std::panic::{catch_unwind, AssertUnwindSafe};
 use std::ptr;
+
+pub mod nls;
+#[cfg(feature = "ida-problem")]
+pub mod problem;
 
 use ida_hip_sys as sys;
 use linear::{LSolver, LSolverType};
@@ -160,10 +172,20 @@ impl Ctx {
         self.raw
     }
 
-    fn last_error(&self) -> String {
+    pub(crate) fn last_error(&self) -> String {
         unsafe { CStr::from_ptr(sys::idahip_last_error(self.raw)).to_string_lossy().into_owned() }
     }
-    fn check(&self, rc: c_int) -> Result<c_int, Error> {
+    /// host -> device copy through the library (no HIP runtime needed by the caller); the return code is checked
+    pub(crate) fn h2d<T>(&self, d: *mut T, h: &[T]) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_memcpy_h2d(self.raw, d as *mut c_void, h.as_ptr() as *const c_void, std::mem::size_of_val(h)) };
+        self.check(rc).map(|_| ())
+    }
+    /// device -> host copy through the library; the return code is checked
+    pub(crate) fn d2h<T>(&self, h: &mut [T], d: *const T) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_memcpy_d2h(self.raw, h.as_mut_ptr() as *mut c_void, d as *const c_void, std::mem::size_of_val(h)) };
+        self.check(rc).map(|_| ())
+    }
+    pub(crate) fn check(&self, rc: c_int) -> Result<c_int, Error> {
         if rc < 0 {
             Err(Error::Library { code: rc, message: self.last_error() })
         } else {
@@ -274,18 +296,19 @@ where
         let mut host: Vec<f64> = mat_a.iter().copied().collect();
         let idx = [0i32];
         let mut info = [0i32];
-        unsafe {
-            sys::idahip_memcpy_h2d(raw, self.d_a as *mut c_void, host.as_ptr() as *const c_void, Self::bytes(n * n));
-            let rc = sys::idahip_ls_setup(raw, self.d_a, self.d_piv, info.as_mut_ptr(), idx.as_ptr(), 1);
-            assert!(rc >= 0, "{}", self.ctx.last_error());
-            if info[0] != 0 {
-                return Err(linear::Error::LUFactFail { col: info[0] as usize }); // 1-based (dense.rs:121)
-            }
-            sys::idahip_memcpy_d2h(raw, host.as_mut_ptr() as *mut c_void, self.d_a as *const c_void, Self::bytes(n * n));
-            sys::idahip_memcpy_d2h(raw, self.pivots.as_mut_ptr() as *mut c_void, self.d_piv as *const c_void, Self::bytes(n));
-        }
+        let lib = |e: Error| -> linear::Error { panic!("{}", e) }; // the trait has no variant for a device failure
+        self.ctx.h2d(self.d_a, &host).map_err(lib)?;
+        let rc = unsafe { sys::idahip_ls_setup(raw, self.d_a, self.d_piv, info.as_mut_ptr(), idx.as_ptr(), 1) };
+        assert!(rc >= 0, "{}", self.ctx.last_error());
+        // dense_get_rf works in place: on a zero pivot the caller's matrix holds the columns eliminated so far (dense.rs:120-122),
+        // so the (partially) factored matrix and the pivots go back in both cases
+        self.ctx.d2h(&mut host, self.d_a as *const f64).map_err(lib)?;
+        self.ctx.d2h(&mut self.pivots, self.d_piv as *const i64).map_err(lib)?;
         for (dst, src) in mat_a.iter_mut().zip(host.iter()) {
             *dst = *src;
+        }
+        if info[0] != 0 {
+            return Err(linear::Error::LUFactFail { col: info[0] as usize }); // 1-based (dense.rs:121)
         }
         Ok(())
     }
@@ -308,15 +331,14 @@ where
         let rhs: Vec<f64> = b.iter().copied().collect();
         let mut out = vec![0.0f64; n];
         let idx = [0i32];
-        unsafe {
-            // the trait hands the factors back in on every call: they are uploaded again, like Dense::solve reads mat_a
-            sys::idahip_memcpy_h2d(raw, self.d_a as *mut c_void, lu.as_ptr() as *const c_void, Self::bytes(n * n));
-            sys::idahip_memcpy_h2d(raw, self.d_piv as *mut c_void, self.pivots.as_ptr() as *const c_void, Self::bytes(n));
-            sys::idahip_memcpy_h2d(raw, self.d_b as *mut c_void, rhs.as_ptr() as *const c_void, Self::bytes(n));
-            let rc = sys::idahip_ls_solve(raw, self.d_a, self.d_piv, self.d_x, self.d_b, 0.0, idx.as_ptr(), 1);
-            assert!(rc >= 0, "{}", self.ctx.last_error());
-            sys::idahip_memcpy_d2h(raw, out.as_mut_ptr() as *mut c_void, self.d_x as *const c_void, Self::bytes(n));
-        }
+        let lib = |e: Error| -> linear::Error { panic!("{}", e) };
+        // the trait hands the factors back in on every call: they are uploaded again, like Dense::solve reads mat_a
+        self.ctx.h2d(self.d_a, &lu).map_err(lib)?;
+        self.ctx.h2d(self.d_piv, &self.pivots).map_err(lib)?;
+        self.ctx.h2d(self.d_b, &rhs).map_err(lib)?;
+        let rc = unsafe { sys::idahip_ls_solve(raw, self.d_a, self.d_piv, self.d_x, self.d_b, 0.0, idx.as_ptr(), 1) };
+        assert!(rc >= 0, "{}", self.ctx.last_error());
+        self.ctx.d2h(&mut out, self.d_x as *const f64).map_err(lib)?;
         for (dst, src) in x.iter_mut().zip(out.iter()) {
             *dst = *src;
         }
@@ -458,8 +480,21 @@ impl HipEnsemble {
         out
     }
 
-    pub fn ctx(&mut self) -> &mut Ctx {
-        &mut self.ctx
+    /// The context the ensemble integrates on (read-only: the ensemble keeps a pointer into it, so it cannot be replaced).
+    pub fn ctx(&self) -> &Ctx {
+        &self.ctx
+    }
+
+    /// `Ctx::set_lu_variant` of the ensemble's context.
+    pub fn set_lu_variant(&mut self, variant: i32) -> Result<(), Error> {
+        self.ctx.set_lu_variant(variant)
+    }
+
+    /// Small device problems (n <= 8): the whole of `Ida::solve` in one launch with the controller on the device (default on).
+    pub fn set_device_controller(&mut self, on: bool) {
+        unsafe {
+            sys::idaens_set_device_controller(self.raw, on as c_int);
+        }
     }
 }
 

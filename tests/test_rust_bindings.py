@@ -13,6 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYS = os.path.join(ROOT, "bindings", "rust", "ida-hip-sys", "src", "lib.rs")
 SAFE = os.path.join(ROOT, "bindings", "rust", "ida-hip", "src", "lib.rs")
+SAFE_ALL = [os.path.join(ROOT, "bindings", "rust", "ida-hip", "src", f) for f in ("lib.rs", "nls.rs", "problem.rs")]
 
 
 def test_sys_crate_is_the_generated_one():
@@ -39,8 +40,15 @@ def test_every_extern_item_is_an_exported_symbol_with_the_headers_arity():
 def test_safe_crate_only_uses_items_of_the_sys_crate():
     sys_txt = open(SYS).read()
     items = set(re.findall(r"pub (?:fn|const|type|struct) (\w+)", sys_txt))
-    used = set(re.findall(r"\bsys::(\w+)", open(SAFE).read()))
+    used = set()
+    for path in SAFE_ALL:
+        used |= set(re.findall(r"\bsys::(\w+)", open(path).read()))
     assert used and used <= items, sorted(used - items)
+    # the trait surface north_star names is there: LSolver, NLSolver, NLProblem, and the IdaProblem bridge
+    txt = "".join(open(path).read() for path in SAFE_ALL)
+    for needle in ("impl<D> LSolver<f64, D> for HipDense<D>", "impl<D> NLSolver<f64, D> for HipNewton<D>",
+                   "impl<D> NLProblem<f64, D> for HipNlsProblem<D>", "impl<P> HostProblem for IdaProblemAdapter<P>"):
+        assert needle in txt, needle
 
 
 def _balanced(path):
@@ -60,7 +68,8 @@ def _balanced(path):
 
 def test_sources_are_lexically_well_formed():
     _balanced(SYS)
-    _balanced(SAFE)
+    for path in SAFE_ALL:
+        _balanced(path)
     for p in ("Cargo.toml", os.path.join("ida-hip-sys", "Cargo.toml"), os.path.join("ida-hip-sys", "build.rs"),
               os.path.join("ida-hip", "Cargo.toml")):
         assert os.path.getsize(os.path.join(ROOT, "bindings", "rust", p)) > 0
