@@ -46,7 +46,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 VALU_FMA_TFLOPS = 78.6       # fp64 vector peak with FMA = 1/2 x 157.3 TFLOP/s fp32 vector (same guide), 2.4 GHz
 VALU_UNFUSED_TFLOPS = 39.3   # a multiply and a subtract per update (the reference's arithmetic, dense.rs:151): half of it
-PMC_SUMMARY = os.path.join("profiles", "r02_bench_summary.json")  # committed rocprofv3 --pmc passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r03_bench_summary.json")  # committed rocprofv3 --pmc passes of this command
 
 
 def algorithmic_bytes(n, workload="linear_dense"):
@@ -85,6 +85,19 @@ def trailing_work(n):
     return flops, nbytes, launches
 
 
+def kernel_sources_sha(root=None):
+    """sha256 over the device sources (rust-ida_amd/csrc/*.hpp, idahip.hip): a profile summary is only valid for the kernels it
+    was taken with."""
+    import glob
+    import hashlib
+    d = os.path.join(root or ROOT, "rust-ida_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.hpp")) + [os.path.join(d, "idahip.hip")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic(kernel_prefix):
     """HBM bytes per matrix of one LU kernel from the committed rocprofv3 PMC summary of this command (separate --pmc
     FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/README.md). Counters cannot be read inside this process, so
@@ -93,10 +106,12 @@ def profiled_traffic(kernel_prefix):
         s = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
     except Exception:
         return None
+    if s.get("kernel_sources_sha") != kernel_sources_sha():
+        return None  # the summary was taken with other kernels than the ones this process runs: not this build's traffic
     tot = sum(v for k, v in s.get("lu_hbm_bytes_per_matrix", {}).items() if k.startswith(kernel_prefix))
     if not tot:
         return None
-    return {"hbm_bytes_per_matrix": int(tot), "source": PMC_SUMMARY, "commit": s.get("commit")}
+    return {"hbm_bytes_per_matrix": int(tot), "source": PMC_SUMMARY, "commit": s.get("commit"), "kernel_sources_sha": s.get("kernel_sources_sha")}
 
 
 def lu_plus_solve(tim, n, arithmetic, dense=True):
@@ -311,19 +326,23 @@ def main():
 
     import torch
     import torch.distributed as dist
-    # Rehearsal knob for a one-GPU box: IDAHIP_BENCH_REHEARSE=1 puts every rank on cuda:0 (or on the CPU-side gloo group
-    # only) and uses gloo for the barrier and the max-time (RCCL refuses two ranks on one device). Never set by the driver;
-    # the JSON line says so.
+    # Rehearsal knob for a one-GPU box: IDAHIP_BENCH_REHEARSE=1 puts every rank on cuda:0. Never set by the driver; the JSON
+    # line says so.
     rehearse = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # The ranks share nothing on the data path (independent IVPs; north_star: "no RCCL required"): the process
+        # group only lines them up (barrier) and combines two scalars (max time, total iterations), on CPU tensors over gloo.
+        # An 8-rank run therefore does not depend on RCCL bring-up. IDAHIP_BENCH_BACKEND=nccl switches to RCCL on device tensors.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
+        backend = os.environ.get("IDAHIP_BENCH_BACKEND", "gloo")
+        if backend == "nccl" and not rehearse:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            backend = "gloo"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -345,7 +364,11 @@ def main():
     elapsed = time.perf_counter() - t0
     iters = run.total_iters() - it0
     barrier()
-    elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cpu" if rehearse else "cuda")
+    elapsed_max, iters_all = sharding.combine(elapsed, iters, dist if world > 1 else None, device="cuda" if (world > 1 and backend == "nccl") else "cpu")
+    per_rank = [iters]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, (int(iters), round(elapsed, 6)))
 
     # ---- untimed repetitions of the same K steps with event timers: per kernel class, then per kernel of the LU
     tim = run.timed_steps(args.steps, 1)
@@ -430,6 +453,16 @@ def main():
                     "traffic": None if tr is None else int(tr["hbm_bytes_per_matrix"] * mats / max(1, v["launches"])),
                     "traffic_bytes_per_matrix": None if tr is None else tr["hbm_bytes_per_matrix"],
                     "traffic_source": None if tr is None else "%s (rocprofv3 --pmc passes of this command at commit %s)" % (tr["source"], tr["commit"])}
+        elif args.n <= 8:
+            # the device-resident stepper: one kernel does everything; timed under the "vector" class
+            d = tim["vector"]
+            nb = 24 * args.n * args.n + 80 * args.n  # algorithmic bytes of one Newton iteration
+            ach = nb * iters_all / (elapsed_max * 1e9) if elapsed_max > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "tiny_ida_kernel (the whole of Ida::solve, one thread per system, controller on the device)",
+                    "share_of_device_time": 1.0, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                    "traffic": None, "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4),
+                    "note": "latency bound: 72-byte matrices, one thread per system (SURVEY 8(d): the roofline fraction is meaningless "
+                            "for this configuration; iterations per second is the figure)"}
         else:
             cls = "lu" if dom.startswith("lu_") else dom  # (banded workload: the getrf as a whole on its algorithmic bytes)
             d = tim[cls]
@@ -457,6 +490,8 @@ def main():
             "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective"},
             "newton_iters_timed": iters_all,
+            "per_rank": None if world == 1 else {"newton_iters": [p[0] for p in per_rank], "seconds": [p[1] for p in per_rank],
+                                                 "process_group": backend + " (barrier and two scalars only; no data-path collective)"},
             "roofline": roof,
             "kernel_classes_rank0": classes,
             "lu_kernels_rank0": lu_kernels,
@@ -472,7 +507,7 @@ def main():
         if TIME_ALL:
             out["timers"] = "IDAHIP_BENCH_TIME_ALL=1: per-kernel LU timers on in every launch of the process, `value` includes their synchronisations"
         if rehearse:
-            out["rehearsal"] = "all ranks on cuda:0 over gloo -- not a scaling measurement"
+            out["rehearsal"] = "all ranks on cuda:0 -- not a scaling measurement"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

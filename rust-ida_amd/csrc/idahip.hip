@@ -579,6 +579,22 @@ int idahip_nls_sys_setup(idahip_ctx* c, const double* hTn, const double* hCj, in
     return factor_and_report(c, work, a.idx, hIdx, nsys, hInfo);
 }
 
+// One Newton iteration body for the listed systems (shared by idahip_newton_iter and idahip_newton_iter2)
+static int launch_newton_iter(idahip_ctx* c, const int* d_idx, const double* d_scale, double* d_out, const int* d_skip, int nsys) {
+    const int n = c->n;
+    if (n <= TINY_N) {
+        hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
+                           (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, d_skip);
+    } else if (n % 2 == 0) {
+        hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+    } else {
+        hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+    }
+    return post_launch(c, "newton_iter");
+}
+
 int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, const int32_t* hIdx, int nsys) {
     DevGuard dev_guard__(c);
     int rc = check_list(c, hIdx, nsys);
@@ -595,38 +611,12 @@ int idahip_newton_iter(idahip_ctx* c, const double* hScale, double* hDelnrm, con
     if ((rc = ap.upload())) return rc;
     {
         KTimer kt(c, IDAHIP_K_NEWTON_ITER, nsys);
-        if (n <= TINY_N) {
-            hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
-                               (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, (const int*)nullptr);
-        } else if (n % 2 == 0) {
-            hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, (const int*)nullptr);
-        } else {
-            hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                               (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, (const int*)nullptr);
-        }
-        if ((rc = post_launch(c, "newton_iter"))) return rc;
+        if ((rc = launch_newton_iter(c, d_idx, d_scale, d_out, nullptr, nsys))) return rc;
     }
     if ((rc = ap.fetch())) return rc;
     const double* h = ap.host_of(d_out);
     for (int s = 0; s < nsys; ++s) hDelnrm[s] = sqrt(h[s] / (double)n);
     return 0;
-}
-
-// One Newton iteration body for the listed systems (shared by idahip_newton_iter and idahip_newton_iter2)
-static int launch_newton_iter(idahip_ctx* c, const int* d_idx, const double* d_scale, double* d_out, const int* d_skip, int nsys) {
-    const int n = c->n;
-    if (n <= TINY_N) {
-        hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
-                           (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, d_skip);
-    } else if (n % 2 == 0) {
-        hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
-    } else {
-        hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
-    }
-    return post_launch(c, "newton_iter");
 }
 
 int idahip_newton_iter2(idahip_ctx* c, const double* hScale, const double* hTn, const double* hCj, const double* hToldel, const double* hSs,

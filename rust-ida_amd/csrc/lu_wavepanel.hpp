@@ -302,6 +302,10 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
                     prow[kc] = pr;
                     ptab[kstep] = pl | (ps << 6);
                 }
+                // ptab is written by lane 0 and read by every lane in the left-looking loop of the later blocks: one wave, LDS
+                // operations in program order -- the fence and the wave barrier only keep the compiler from reordering them
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 static_for<0, NSC>([&](auto st) {
                     constexpr int S = decltype(st)::value;
                     if (pstep[S] == BIG && rpos[S] == kc) rpos[S] = bp;  // the row that sat at position k moves to the pivot's old position
@@ -373,6 +377,8 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
                 const unsigned long long bm = __ballot(mine);
                 if (bm != 0ull && lane == 0) ptab[k] = ((int)__ffsll((unsigned long long)bm) - 1) | (S << 6);
             });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) w.redo[b] = 0;
     }

@@ -176,8 +176,15 @@ class Ctx:
 
     def _chk(self, rc, what):
         if rc < 0:
-            raise IdaHipError("%s failed (%d): %s" % (what, rc, self.H.idahip_last_error(self.h).decode()))
+            self.fail("%s failed (%d): %s" % (what, rc, self.H.idahip_last_error(self.h).decode()))
         return rc
+
+    def fail(self, message):
+        """Raise IdaHipError; an exception raised inside a host callback (it could not cross the C boundary) is its cause."""
+        cause, self._cb_error = getattr(self, "_cb_error", None), None
+        if cause is not None:
+            raise IdaHipError(message + " [Python callback raised %s: %s]" % (type(cause).__name__, cause)) from cause
+        raise IdaHipError(message)
 
     def all_idx(self):
         return np.arange(self.batch, dtype=np.int32)
@@ -201,23 +208,25 @@ class Ctx:
         None entries left zero. Python callables are wrapped into the C callbacks of include/ida_hip.h."""
         n = self.n
 
+        self._cb_error = None  # the exception a callback raised: it cannot cross the C boundary, so it is kept and re-raised by _chk
+
         def c_res(sys, t, yy, yp, out, _user):
             try:
                 r = res(sys, t, np.ctypeslib.as_array(yy, (n,)), np.ctypeslib.as_array(yp, (n,)))
-                for i in range(n):
-                    out[i] = r[i]
+                np.copyto(np.ctypeslib.as_array(out, (n,)), np.asarray(r, dtype=np.float64).reshape(n))
                 return 0
-            except Exception:  # an exception must not cross the C boundary
+            except Exception as e:
+                self._cb_error = e
                 return 1
 
         def c_jac(sys, t, cj, yy, yp, rv, J, _user):
             try:
                 m = jac(sys, t, cj, np.ctypeslib.as_array(yy, (n,)), np.ctypeslib.as_array(yp, (n,)), np.ctypeslib.as_array(rv, (n,)))
-                for i in range(n):
-                    for j in range(n):
-                        J[j * n + i] = m[i][j]  # column-major
+                # m[i][j] = dF_i/dy_j (row, column); the library's matrix is column-major: J[j * n + i]
+                np.copyto(np.ctypeslib.as_array(J, (n, n)), np.asarray(m, dtype=np.float64).reshape(n, n).T)
                 return 0
-            except Exception:
+            except Exception as e:
+                self._cb_error = e
                 return 1
 
         self._cb = (RES_FN(c_res), JAC_FN(c_jac))  # keep the thunks alive as long as the ctx
@@ -400,7 +409,7 @@ class Ensemble:
         h = C.c_void_p()
         rc = self.E.idaens_create(C.byref(h), ctx.h, _p(yy0), _p(yp0))
         if rc != 0:
-            raise IdaHipError("idaens_create failed (%d): %s" % (rc, ctx.H.idahip_last_error(ctx.h).decode()))
+            self.ctx.fail("idaens_create failed (%d): %s" % (rc, ctx.H.idahip_last_error(ctx.h).decode()))
         self.h = h
         ctx._ensembles = getattr(ctx, "_ensembles", 0) + 1
 
@@ -448,7 +457,7 @@ class Ensemble:
         status = np.zeros(self.ctx.batch, dtype=np.int32)
         rc = self.E.idaens_solve(self.h, float(tout), int(itask), _p(tret), _p(status, i32p), int(max_rounds))
         if rc < 0:
-            raise IdaHipError("idaens_solve failed (%d): %s" % (rc, self.E.idaens_last_error(self.h).decode()))
+            self.ctx.fail("idaens_solve failed (%d): %s" % (rc, self.E.idaens_last_error(self.h).decode()))
         return status, tret
 
     def solve_schedule(self, touts, max_rounds=0, outputs=False):
@@ -464,7 +473,7 @@ class Ensemble:
         rc = self.E.idaens_solve_schedule(self.h, _p(touts), touts.size, _p(tret), _p(status, i32p), _p(reached, i32p),
                                           _p(yo) if outputs else None, _p(ypo) if outputs else None, int(max_rounds))
         if rc < 0:
-            raise IdaHipError("idaens_solve_schedule failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+            self.ctx.fail("idaens_solve_schedule failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
         return (status, tret, reached, yo, ypo) if outputs else (status, tret, reached)
 
     def stream(self, touts, max_rounds, stagger_rounds=0):
@@ -475,7 +484,7 @@ class Ensemble:
         done = C.c_int64(0)
         rc = self.E.idaens_stream(self.h, _p(touts), touts.size, int(max_rounds), int(stagger_rounds), C.byref(done))
         if rc < 0:
-            raise IdaHipError("idaens_stream failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+            self.ctx.fail("idaens_stream failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
         return done.value
 
     def counter(self, name):
@@ -507,7 +516,7 @@ class Ensemble:
         status = np.zeros(self.ctx.batch, dtype=np.int32)
         rc = self.E.idaens_get_dky(self.h, float(t), int(k), _p(out), _p(status, i32p))
         if rc < 0:
-            raise IdaHipError("idaens_get_dky failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
+            self.ctx.fail("idaens_get_dky failed (%d): %s" % (rc, (self.E.idaens_last_error(self.h) or b"").decode()))
         return status, out
 
     def total_newton_iters(self):

@@ -3,10 +3,13 @@
 summary committed under profiles/. HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE / WRITE_SIZE are in KiB of 64-B requests; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced
 streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B-per-lane stores.
-usage: summarize_profiles.py <stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <bench.json> <out.json>"""
+An optional SQ-counter pass (SQ_* of the same command) is folded in per kernel: busy fractions of the vector ALU and the LDS,
+wait fractions, so that "what bounds this kernel" can be read from the committed file.
+usage: summarize_profiles.py <stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <bench.json> <out.json> [sq_counter_collection.csv ...]"""
 import collections, csv, json, sys
 
 stats, fetch, write, bench, out = sys.argv[1:6]
+sq_files = sys.argv[6:]
 short = lambda n: n.split("(")[0].replace("void ", "").replace("idahip::", "")
 k = {}
 for r in csv.DictReader(open(stats)):
@@ -27,10 +30,39 @@ for name, d in k.items():
         d["hbm_write_GB_total"] = round(w.get(name, 0.0) * 1024 / 1e9, 3)
         d["hbm_bytes_per_launch"] = int((2.0 * f[name] + w.get(name, 0.0)) * 1024 / max(1, fc[name]))
         d["hbm_GBps"] = round((2.0 * f[name] + w.get(name, 0.0)) * 1024 / 1e9 / (d["total_ms"] / 1e3), 1)
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+for path in sq_files:
+    for r in csv.DictReader(open(path)):
+        sq[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+for name, c in sq.items():
+    if name not in k:
+        continue
+    d = {kk: vv for kk, vv in c.items()}
+    wc_, bc_ = c.get("SQ_WAVE_CYCLES", 0.0), c.get("SQ_BUSY_CYCLES", 0.0)
+    der = {}
+    # SQ_ACTIVE_INST_* count cycles (x4 per SIMD quad on gfx9) in which a wave of that SIMD issues to the unit; fractions are of
+    # the busy cycles of the shader engines' sequencers -- see DESIGN.md section 4 for how they are read
+    if bc_ > 0:
+        for cn in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY"):
+            if cn in c:
+                der[cn + "/SQ_BUSY_CYCLES"] = round(c[cn] / bc_, 4)
+    if wc_ > 0:
+        for cn in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS"):
+            if cn in c:
+                der[cn + "/SQ_WAVE_CYCLES"] = round(c[cn] / wc_, 4)
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        der["SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+    k[name]["sq_counters"] = {kk: float("%.6g" % vv) for kk, vv in sorted(d.items())}
+    k[name]["sq_derived"] = der
 import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import importlib.util
+_spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+_bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bench)
 b = json.loads(open(bench).read().strip().splitlines()[-1])
 lu_mats = b["kernel_classes_rank0"]["lu"]["systems"]
-res = {"commit": os.environ.get("GIT_COMMIT", "unknown"),
+res = {"commit": os.environ.get("GIT_COMMIT", "unknown"), "kernel_sources_sha": _bench.kernel_sources_sha(),
        "bench": {**{kk: b[kk] for kk in ("value", "steps", "warmup", "ms_per_step", "kernel_classes_rank0") if kk in b},
                  "lu_kernels_rank0": b.get("lu_kernels_rank0"), "lu_matrices": lu_mats},
        "kernels": k,
