@@ -72,6 +72,11 @@ struct idahip_ctx {
     uint64_t* tiny_acc = nullptr;
     int tiny_ntout_cap = 0, tiny_yout_cap = 0;
 
+    // device-resident lock-step stepper (round_ida.hpp): per-system round state, the LU list, the round summary (lazy)
+    int32_t* rnd_i = nullptr;   // 8 int arrays of length batch + lu_cnt[1] + summary[2]
+    double* rnd_d = nullptr;    // 4 double arrays of length batch
+    int32_t* rnd_host = nullptr;  // pinned: the round summary
+
     // problem data
     double* params = nullptr;  // [batch][nparam]
     int nparam = 0;

@@ -6,6 +6,7 @@
 #include "solve_kernels.hpp"
 #include "vector_kernels.hpp"
 #include "tiny_ida.hpp"
+#include "round_ida.hpp"
 
 using namespace idahip;
 
@@ -135,9 +136,10 @@ int idahip_destroy(idahip_ctx* c) {
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
-                    c->tiny_acc};
+                    c->tiny_acc, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->rnd_host) (void)hipHostFree(c->rnd_host);
     for (int i = 0; i < NSLOT; ++i) {
         if (c->slots[i].h) (void)hipHostFree(c->slots[i].h);
         if (c->slots[i].d) (void)hipFree(c->slots[i].d);
@@ -944,6 +946,21 @@ int idahip_pow_batch(idahip_ctx* c, const double* hX, const double* hY, double* 
     return rc;
 }
 
+static int stepper_buffers(idahip_ctx* c, const idahip_tiny_call* call, bool outputs);
+
+// the schedule and the limits of a stepper call as the device-resident steppers take them (touts and start rounds already on
+// the device)
+static FlowArgs flow_args(idahip_ctx* c, const idahip_tiny_call* call) {
+    FlowArgs f;
+    f.touts = c->tiny_touts; f.ntout = call->ntout; f.recycle = call->recycle; f.resume = call->resume;
+    f.mxstep = call->mxstep; f.maxord = call->maxord; f.maxnef = call->maxnef; f.maxncf = call->maxncf;
+    f.epcon = call->epcon; f.hmax_inv = call->hmax_inv; f.t0 = call->t0;
+    f.start_round = call->start_round ? (const long long*)c->tiny_start : nullptr;
+    f.acc = (unsigned long long*)c->tiny_acc;
+    f.batch = c->batch;
+    return f;
+}
+
 int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
                       double* hYout, double* hYPout) {
     DevGuard dev_guard__(c);
@@ -955,28 +972,9 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;
-    int rc = 0;
-    if (!c->tiny_sys) {
-        IDAHIP_HIP(c, hipMalloc(&c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore)));
-        rc |= dalloc(c, &c->tiny_start, (size_t)batch);
-        rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
-        rc |= dalloc(c, &c->tiny_acc, (size_t)2);
-        if (rc) return rc;
-    }
-    if (call->ntout > c->tiny_ntout_cap) {
-        if (c->tiny_touts) (void)hipFree(c->tiny_touts);
-        if ((rc = dalloc(c, &c->tiny_touts, (size_t)call->ntout))) return rc;
-        c->tiny_ntout_cap = call->ntout;
-    }
+    int rc = stepper_buffers(c, call, hYout || hYPout);
+    if (rc) return rc;
     const size_t ysz = (size_t)call->ntout * batch * n;
-    if ((hYout || hYPout) && call->ntout > c->tiny_yout_cap) {
-        if (c->tiny_yout) (void)hipFree(c->tiny_yout);
-        if (c->tiny_ypout) (void)hipFree(c->tiny_ypout);
-        c->tiny_yout = c->tiny_ypout = nullptr;
-        if ((rc = dalloc(c, &c->tiny_yout, ysz))) return rc;
-        if ((rc = dalloc(c, &c->tiny_ypout, ysz))) return rc;
-        c->tiny_yout_cap = call->ntout;
-    }
     IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_sys, hSys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyHostToDevice, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_touts, call->touts, sizeof(double) * call->ntout, hipMemcpyHostToDevice, c->stream));
     if (call->start_round)
@@ -987,16 +985,12 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     a.v = vec_state(c);
     a.savres = c->savres; a.lu = c->lu; a.piv = (long long*)c->piv; a.params = c->params; a.nparam = c->nparam;
     a.ic_y = c->ic_y; a.ic_yp = c->ic_yp;
-    a.touts = c->tiny_touts; a.ntout = call->ntout; a.recycle = call->recycle; a.resume = call->resume;
-    a.max_rounds = call->max_rounds; a.mxstep = call->mxstep; a.maxord = call->maxord; a.maxnef = call->maxnef; a.maxncf = call->maxncf;
-    a.epcon = call->epcon; a.hmax_inv = call->hmax_inv; a.t0 = call->t0;
-    a.start_round = call->start_round ? (const long long*)c->tiny_start : nullptr;
+    a.f = flow_args(c, call);
+    a.max_rounds = call->max_rounds;
     a.round_base = call->round_base;
     a.yout = hYout ? c->tiny_yout : nullptr;
     a.ypout = hYPout ? c->tiny_ypout : nullptr;
     a.rounds_done = (long long*)c->tiny_rounds;
-    a.acc = (unsigned long long*)c->tiny_acc;
-    a.batch = batch;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, batch);
         if (c->kind == IDAHIP_ROBERTS) hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_ROBERTS>, dim3((batch + 63) / 64), dim3(64), 0, c->stream, a);
@@ -1011,6 +1005,155 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+
+// buffers every device-resident stepper call needs: controller states, the schedule, the stagger, counters, output slots
+static int stepper_buffers(idahip_ctx* c, const idahip_tiny_call* call, bool outputs) {
+    const int batch = c->batch, n = c->n;
+    int rc = 0;
+    if (!c->tiny_sys) {
+        IDAHIP_HIP(c, hipMalloc(&c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore)));
+        rc |= dalloc(c, &c->tiny_start, (size_t)batch);
+        rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
+        rc |= dalloc(c, &c->tiny_acc, (size_t)2);
+        if (rc) return rc;
+    }
+    if (call->ntout > c->tiny_ntout_cap) {
+        if (c->tiny_touts) (void)hipFree(c->tiny_touts);
+        c->tiny_touts = nullptr;
+        if ((rc = dalloc(c, &c->tiny_touts, (size_t)call->ntout))) return rc;
+        c->tiny_ntout_cap = call->ntout;
+    }
+    if (outputs && call->ntout > c->tiny_yout_cap) {
+        const size_t ysz = (size_t)call->ntout * batch * n;
+        if (c->tiny_yout) (void)hipFree(c->tiny_yout);
+        if (c->tiny_ypout) (void)hipFree(c->tiny_ypout);
+        c->tiny_yout = c->tiny_ypout = nullptr;
+        if ((rc = dalloc(c, &c->tiny_yout, ysz))) return rc;
+        if ((rc = dalloc(c, &c->tiny_ypout, ysz))) return rc;
+        c->tiny_yout_cap = call->ntout;
+    }
+    return 0;
+}
+
+int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
+                       double* hYout, double* hYPout, int64_t* rounds_run) {
+    DevGuard dev_guard__(c);
+    if (!c) return -1;
+    if (!hSys || !call || !hRoundsDone || !hAcc || !rounds_run || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
+    if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
+    if (c->n <= TINY_N || c->n > WP_MAX_ROWS || c->kind != IDAHIP_LINEAR_DENSE || c->lu_variant < 4)
+        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4 or 5)", TINY_N, WP_MAX_ROWS);
+    if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
+    if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
+    const int batch = c->batch, n = c->n;
+    const long nn = (long)n * n;
+    int rc = stepper_buffers(c, call, hYout || hYPout);
+    if (rc) return rc;
+    if (!c->rnd_i) {
+        rc |= dalloc(c, &c->rnd_i, (size_t)8 * batch + 6 + 2 * IDAHIP_K_COUNT);
+        rc |= dalloc(c, &c->rnd_d, (size_t)4 * batch);
+        if (rc) return rc;
+        IDAHIP_HIP(c, hipHostMalloc((void**)&c->rnd_host, 4 * sizeof(int32_t)));
+    }
+    const size_t ysz = (size_t)call->ntout * batch * n;
+    IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_sys, hSys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyHostToDevice, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_touts, call->touts, sizeof(double) * call->ntout, hipMemcpyHostToDevice, c->stream));
+    if (call->start_round)
+        IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_start, call->start_round, sizeof(int64_t) * batch, hipMemcpyHostToDevice, c->stream));
+    IDAHIP_HIP(c, hipMemsetAsync(c->tiny_acc, 0, 2 * sizeof(uint64_t), c->stream));
+    RoundArgs a;
+    a.f = flow_args(c, call);
+    a.sys = (idactl::SysCore*)c->tiny_sys;
+    a.v = vec_state(c);
+    a.ic_y = c->ic_y; a.ic_yp = c->ic_yp;
+    a.yout = hYout ? c->tiny_yout : nullptr;
+    a.ypout = hYPout ? c->tiny_ypout : nullptr;
+    a.round_base = call->round_base;
+    int* ib = c->rnd_i;
+    a.stepping = ib; a.in_newton = ib + batch; a.skipP = ib + 2 * batch; a.skipL = ib + 3 * batch; a.skipI = ib + 4 * batch;
+    a.skipS = ib + 5 * batch; a.ident = ib + 6 * batch; a.lu_list = ib + 7 * batch; a.lu_cnt = ib + 8 * batch; a.summary = ib + 8 * batch + 1;
+    a.stats = (unsigned long long*)(ib + 8 * batch + 4);  // (8 * batch + 4 ints: 8-byte aligned for even batch; checked below)
+    if (((uintptr_t)a.stats & 7) != 0) a.stats = (unsigned long long*)(ib + 8 * batch + 5);
+    IDAHIP_HIP(c, hipMemsetAsync(a.stats, 0, IDAHIP_K_COUNT * sizeof(unsigned long long), c->stream));
+    a.lu_info = c->lu_info;
+    a.tn = c->rnd_d; a.cj = c->rnd_d + batch; a.scale = c->rnd_d + 2 * batch; a.nrm_out = c->rnd_d + 3 * batch;
+    a.rounds_done = (long long*)c->tiny_rounds;
+    hipLaunchKernelGGL(round_init_kernel, dim3((batch + 255) / 256), dim3(256), 0, c->stream, a);
+    IDAHIP_HIP(c, hipMemsetAsync(a.summary, 0, 2 * sizeof(int), c->stream));
+    const size_t shm_wg = sizeof(double) * (4 * (size_t)n + 8);
+    const size_t shm_it = 2 * sizeof(double) * n;
+    SysArgs sa;
+    fill_sys_args(c, sa, 1);
+    sa.idx = a.ident; sa.tn = a.tn; sa.cj = a.cj;
+    int64_t r = 0;
+    for (;; ++r) {
+        if (call->max_rounds > 0 && r >= call->max_rounds) break;
+        a.round = r;
+        a.first_round = r == 0;
+        {
+            KTimer kt(c, IDAHIP_K_VECTOR, 0);
+            hipLaunchKernelGGL(round_begin_kernel, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            hipLaunchKernelGGL(round_lists_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+        }
+        {   // sys(y0), y <- y0 = 0 (newton.rs:73): without and with the Jacobian (J = B + cj A falls out of the same sweep)
+            KTimer kt(c, IDAHIP_K_SYS, 0);
+            sa.reset_ee = 1; sa.skip = a.skipP;
+            if ((rc = launch_sys(c, sa, batch, nullptr))) return rc;
+        }
+        {
+            KTimer kt(c, IDAHIP_K_SYS_JAC, 0);
+            sa.skip = a.skipL;
+            if ((rc = launch_sys(c, sa, batch, c->jw))) return rc;
+        }
+        {
+            KTimer kt(c, IDAHIP_K_LU, 0);
+            if ((rc = lu_factor_batched(c, c->jw, nn, c->lu, nn, (long long*)c->piv, n, c->perm, a.lu_list, batch, a.lu_cnt))) return rc;
+            if ((rc = post_launch(c, "lu"))) return rc;
+        }
+        hipLaunchKernelGGL(round_newton_ctl_kernel, dim3((batch + 255) / 256), dim3(256), 0, c->stream, a, 0);
+        for (int m = 1; m <= idactl::MAXNLSIT; ++m) {
+            {
+                KTimer kt(c, IDAHIP_K_NEWTON_ITER, 0);
+                if ((rc = launch_newton_iter(c, a.ident, a.scale, a.nrm_out, a.skipI, batch))) return rc;
+            }
+            hipLaunchKernelGGL(round_newton_ctl_kernel, dim3((batch + 255) / 256), dim3(256), 0, c->stream, a, m);
+            if (m < idactl::MAXNLSIT) {
+                KTimer kt(c, IDAHIP_K_SYS, 0);
+                sa.reset_ee = 0; sa.skip = a.skipS;
+                if ((rc = launch_sys(c, sa, batch, nullptr))) return rc;
+            }
+        }
+        IDAHIP_HIP(c, hipMemsetAsync(a.summary, 0, sizeof(int), c->stream));
+        {
+            KTimer kt(c, IDAHIP_K_VECTOR, 0);
+            hipLaunchKernelGGL(round_end_kernel, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            if ((rc = post_launch(c, "round_end"))) return rc;
+        }
+        if (!call->recycle) {  // one synchronisation per round: does any system still step?
+            IDAHIP_HIP(c, hipMemcpyAsync(c->rnd_host, a.summary, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->rnd_host[0] == 0) {
+                ++r;
+                break;
+            }
+        }
+    }
+    (void)shm_it;
+    *rounds_run = r;
+    IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(hRoundsDone, c->tiny_rounds, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipMemcpyAsync(hAcc, c->tiny_acc, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (hYout) IDAHIP_HIP(c, hipMemcpyAsync(hYout, c->tiny_yout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));
+    if (hYPout) IDAHIP_HIP(c, hipMemcpyAsync(hYPout, c->tiny_ypout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long hstats[IDAHIP_K_COUNT];
+    IDAHIP_HIP(c, hipMemcpyAsync(hstats, a.stats, sizeof hstats, hipMemcpyDeviceToHost, c->stream));
+    IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < IDAHIP_K_COUNT; ++k) c->k_systems[k] += (int64_t)hstats[k];  // systems actually served, per kernel class
+    c->k_systems[IDAHIP_K_VECTOR] += 2 * r * (int64_t)batch;
+    return 0;
+}
+
+int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
     DevGuard dev_guard__(c);

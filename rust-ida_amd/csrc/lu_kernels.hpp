@@ -32,6 +32,8 @@ struct LuWs {
     double* mats;      // work matrices (physical row order), column-major n x n
     long mstride;      // elements between consecutive systems
     const int* idx;    // [nsys] system ids (device)
+    const int* cnt;    // null, or the length of idx on the device: launches are then sized for the worst case and the surplus
+                       // workgroups leave at once (the device-resident lock-step stepper does not know the list's length on the host)
     int n;
     int* pos;          // [batch][n] physical row -> current reference position
     int* live;         // [batch][n] sorted physical indices of not-yet-pivoted rows
@@ -48,6 +50,7 @@ struct LuWs {
 constexpr int L11_STRIDE = 64 * 64;  // elements per system in LuWs::l11
 
 __global__ void lu_init_kernel(LuWs w) {
+    if (w.cnt && (int)blockIdx.x >= *w.cnt) return;
     const int b = w.idx[blockIdx.x];
     for (int i = threadIdx.x; i < w.n; i += blockDim.x) {
         w.pos[(long)b * w.n + i] = i;
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     constexpr int NB = 64, KC = 32;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
-    if (mi >= nsys) return;
+    if (mi >= (w.cnt ? ldc(w.cnt) : nsys)) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -1066,6 +1069,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 // entries are skipped here -- the work matrix no longer holds them (sp_lead: see below).
 __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __restrict__ out, long ostride, int* __restrict__ perm,
                                                           int cols_per_block, int sp, int sp_lead, int wp_rows) {
+    if (w.cnt && (int)blockIdx.x >= *w.cnt) return;
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;

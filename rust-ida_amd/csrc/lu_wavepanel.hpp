@@ -59,6 +59,7 @@ __device__ __forceinline__ double opaque_vgpr(double u) {
 template <bool FMA, bool SLOWK, int NS>
 __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void lu_wavepanel_kernel(LuWs w, const int k0) {
     constexpr int BIG = 1 << 20;  // pstep of a row that is still live
+    if (w.cnt && (int)blockIdx.x >= *w.cnt) return;
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;

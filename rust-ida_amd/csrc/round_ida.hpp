@@ -1,0 +1,358 @@
+// Device-resident LOCK-STEP stepper for larger systems (8 < n <= 512, device residual): a round = one step attempt of every
+// system that is stepping, as in host/ensemble_ida.cpp -- but the scalar controller of every system lives on the device, the
+// index lists are built there, and the host only enqueues the round's fixed sequence of launches. No host round trip inside a
+// round; in throughput mode (idaens_stream, a fixed number of rounds) none at all between rounds.
+//
+// One round:
+//   round_begin_kernel   workgroup / system: loop-top checks, begin_attempt (set_coeffs, lsetup decision), prediction
+//   round_lists_kernel   one workgroup: the list of systems whose Newton solve starts with a linear setup (+ its length)
+//   sys / sys+jac        the residual kernels of problem_kernels.hpp over the whole batch, each system skipped by one of them
+//   lu_factor_batched    on the device-built list (launches sized for the worst case; surplus workgroups leave at once)
+//   4 x { newton_iter_kernel ; round_newton_ctl_kernel (idaNlsConvTest and Newton's bookkeeping, thread / system) ; sys }
+//   round_end_kernel     workgroup / system: final yy/yp + error-test norms, test_error / handle_n_flag / complete_step,
+//                        stop tests, interpolation to tout, the next tout of the schedule, Ida::new again when streaming
+// The control flow is ida_flow.hpp's (shared with the one-thread-per-system stepper), the decisions ida_controller.hpp's
+// (shared with the host stepper). A Newton solve that ends in ConvergenceRecover with a stale Jacobian (newton.rs:146-152:
+// set up again, iterate again) continues in the NEXT round's setup and iteration passes instead of extending this round: a
+// system's own sequence of operations -- hence its results -- is unchanged, only the round in which they happen is.
+#pragma once
+#include "ida_flow.hpp"
+#include "solve_kernels.hpp"
+#include "vector_kernels.hpp"
+
+namespace idahip {
+
+struct RoundArgs {
+    FlowArgs f;
+    idactl::SysCore* sys;   // [batch]
+    VecState v;
+    const double *ic_y, *ic_yp;
+    double *yout, *ypout;   // [ntout][batch][n] or null
+    long long round_base;   // rounds completed before this launch sequence started
+    long long round;        // index of this round within the call
+    int first_round;        // systems enter the call in this round
+    // per-system round state (device arrays of length batch)
+    int* stepping;          // the system takes step attempts
+    int* in_newton;         // the system's Newton solve is under way in this round
+    int* skipP;             // residual kernel without setup: nonzero = not this system
+    int* skipL;             // residual + Jacobian kernel and LU list
+    int* skipI;             // newton_iter_kernel
+    int* skipS;             // residual kernel inside the iteration passes
+    int* ident;             // 0, 1, 2, ...: the kernels' index list
+    int* lu_list;           // systems to factor
+    int* lu_cnt;            // [1]
+    const int* lu_info;     // [batch] zero-pivot flags of the last factorisation
+    double* tn;             // [batch] arguments of the residual kernels
+    double* cj;
+    double* scale;          // newton_iter_kernel's 2 / (1 + cjratio)
+    double* nrm_out;        // newton_iter_kernel's sum of squares
+    long long* rounds_done; // [batch]
+    unsigned long long* stats;  // [IDAHIP_K_COUNT] systems served per kernel class in this call (the event timers' bookkeeping)
+    int* summary;           // [2]: systems stepping after this round (zeroed before every round), systems that failed (this call)
+};
+
+// vector backend of IdaFlow: a workgroup of WG_NT threads (one wavefront: every thread carries its own copy of the controller
+// state, so fewer threads mean less redundant scalar work and private-memory traffic) owns system b; sums are accumulated left to right by one lane
+// (seq_sum_lds) and broadcast through LDS, exactly as the batched kernels of vector_kernels.hpp do
+constexpr int WG_NT = 64;
+
+struct WgVec {
+    const RoundArgs& a;
+    const int b, n;
+    const long vb;
+    double* sm;  // LDS: 4 * n doubles of summands + 8 doubles of results
+
+    __device__ double& phi(int j, int i) const { return a.v.phi[j * a.v.phistride + vb + i]; }
+    __device__ double* res() const { return sm + 4 * n; }
+
+    __device__ void init_first(double* ypnorm, double* p0nrm) const {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            const double y = phi(0, i);
+            const double e = ewt_of(a.v, y, i);
+            a.v.ewt[vb + i] = e;
+            const double p = phi(1, i) * e;
+            sm[i] = p * p;
+            const double q = y * e;
+            sm[n + i] = q * q;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) res()[threadIdx.x] = seq_sum_lds(sm + threadIdx.x * n, n);
+        __syncthreads();
+        *ypnorm = sqrt(res()[0] / (double)n);
+        *p0nrm = sqrt(res()[1] / (double)n);
+    }
+    __device__ void scale_phi1(double f) const {
+        for (int i = threadIdx.x; i < n; i += WG_NT) phi(1, i) *= f;
+    }
+    __device__ void predict(const idactl::SysCore& s) const {
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            double yyp = 0.0, ypp = 0.0;
+            for (int j = 0; j <= s.kk; ++j) {
+                double p = phi(j, i);
+                if (j >= s.ns) {
+                    p *= s.beta[j];
+                    phi(j, i) = p;
+                }
+                yyp = yyp + p;
+                if (j >= 1) ypp = ypp + s.gamma[j] * p;
+            }
+            a.v.yypredict[vb + i] = yyp;
+            a.v.yppredict[vb + i] = ypp;
+        }
+    }
+    __device__ void post_newton(const idactl::SysCore& s, double* norms) const {
+        const int kk = s.kk;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            const double e = a.v.ee[vb + i];
+            const double w = a.v.ewt[vb + i];
+            a.v.yy[vb + i] = a.v.yypredict[vb + i] + e;
+            a.v.yp[vb + i] = a.v.yppredict[vb + i] + s.cj * e;
+            double p = e * w;
+            sm[i] = p * p;
+            double d = 0.0;
+            if (kk > 1) {
+                d = phi(kk, i) + e;
+                p = d * w;
+                sm[n + i] = p * p;
+            } else {
+                sm[n + i] = 0.0;
+            }
+            if (kk > 2) {
+                d = d + phi(kk - 1, i);
+                p = d * w;
+                sm[2 * n + i] = p * p;
+            } else {
+                sm[2 * n + i] = 0.0;
+            }
+            if (kk + 1 < MXORDP1) {
+                const double tmp = e - phi(kk + 1, i);
+                p = tmp * w;
+                sm[3 * n + i] = p * p;
+            } else {
+                sm[3 * n + i] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) res()[threadIdx.x] = seq_sum_lds(sm + threadIdx.x * n, n);
+        __syncthreads();
+        for (int k = 0; k < 4; ++k) norms[k] = sqrt(res()[k] / (double)n);
+    }
+    __device__ void restore_vec(const idactl::SysCore& s, int kk_att, int ns_att) const {
+        if (ns_att > kk_att) return;
+        for (int i = threadIdx.x; i < n; i += WG_NT)
+            for (int j = ns_att; j <= kk_att; ++j) phi(j, i) *= s.cvals[j - ns_att];
+    }
+    __device__ void complete_step_vec(idactl::SysCore& s, int kused, double ck, int maxord) const {
+        __syncthreads();
+        if (threadIdx.x == 0) res()[1] = 0.0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            const double e = a.v.ee[vb + i];
+            if (kused < maxord) phi(kused + 1, i) = e;
+            double tmp = e;
+            for (int j = kused; j >= 0; --j) {
+                tmp = tmp + phi(j, i);
+                phi(j, i) = tmp;
+            }
+            a.v.ee[vb + i] = e * ck;
+            const double w = ewt_of(a.v, tmp, i);
+            a.v.ewt[vb + i] = w;
+            if (!(w > 0.0)) res()[1] = 1.0;
+            const double p = tmp * w;
+            sm[i] = p * p;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) res()[0] = seq_sum_lds(sm, n);
+        __syncthreads();
+        s.phi0nrm = sqrt(res()[0] / (double)n);
+        s.ewt_bad = res()[1] != 0.0;
+    }
+    __device__ void get_solution_vec(const idactl::SysCore& s, int kord) const {
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            double y = 0.0, yp = 0.0;
+            for (int j = 0; j <= kord; ++j) {
+                const double p = phi(j, i);
+                y = y + s.cvals[j] * p;
+                if (j >= 1) yp = yp + s.dvals[j - 1] * p;
+            }
+            a.v.yy[vb + i] = y;
+            a.v.yp[vb + i] = yp;
+        }
+    }
+    __device__ void emit_output(int slot) const {
+        // (yy / yp were written by this thread's own get_solution_vec just before, same index mapping: no barrier needed)
+        if (a.yout)
+            for (int i = threadIdx.x; i < n; i += WG_NT) a.yout[((long)slot * a.f.batch + b) * n + i] = a.v.yy[vb + i];
+        if (a.ypout)
+            for (int i = threadIdx.x; i < n; i += WG_NT) a.ypout[((long)slot * a.f.batch + b) * n + i] = a.v.yp[vb + i];
+    }
+    __device__ void restore_initial() const {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += WG_NT) {
+            const double y = a.ic_y[vb + i], yp = a.ic_yp[vb + i];
+            phi(0, i) = y;
+            phi(1, i) = yp;
+            a.v.yy[vb + i] = y;
+            a.v.yp[vb + i] = yp;
+        }
+        __syncthreads();
+    }
+};
+
+// ---- begin of a round: who steps, begin_attempt + prediction, which residual kernel serves the system
+__global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
+    extern __shared__ __align__(16) double sm[];
+    const int b = blockIdx.x;
+    idactl::SysCore s = a.sys[b];
+    WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
+    const IdaFlow<WgVec> F{a.f, s, v};
+    const long long ground = a.round_base + a.round;
+    bool stepping = a.first_round ? F.enter(ground, b) : (a.stepping[b] != 0);
+    int kind = 0;  // 1: residual only, 2: residual + Jacobian + LU
+    if (stepping) {
+        if (s.newton_retry) {
+            kind = 2;  // the Newton solve of the running attempt starts over with a linear setup (call_lsetup is set)
+            s.newton_retry = false;
+        } else if (s.ph == idactl::PH_LOOP_TOP && !F.loop_top()) {
+            stepping = false;
+        } else {
+            F.attempt_begin();
+            kind = s.call_lsetup ? 2 : 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.sys[b] = s;
+        a.stepping[b] = stepping ? 1 : 0;
+        a.in_newton[b] = kind != 0;
+        a.skipP[b] = kind != 1;
+        a.skipL[b] = kind != 2;
+        a.skipI[b] = 1;
+        a.skipS[b] = 1;
+        a.tn[b] = s.tn;
+        a.cj[b] = s.cj;
+        if (kind != 0) a.rounds_done[b] += 1;
+        if (kind == 1) atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
+        if (kind == 2) {
+            atomicAdd(&a.stats[IDAHIP_K_SYS_JAC], 1ull);
+            atomicAdd(&a.stats[IDAHIP_K_LU], 1ull);
+        }
+    }
+}
+
+// ---- the list of systems to factor (ascending system id) and its length; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void round_lists_kernel(RoundArgs a) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < a.f.batch; b0 += 1024) {
+        const int b = b0 + t;
+        const bool in = b < a.f.batch && a.skipL[b] == 0;
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int q = 0; q < wave; ++q) off += s_wave[q];
+        if (in) a.lu_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int q = 0; q < 16; ++q) tot += s_wave[q];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (t == 0) a.lu_cnt[0] = s_base;
+}
+
+// ---- Newton's bookkeeping between the batched kernels (newton.rs:73-153, ida_nls.rs:168-179, 218-266); one thread per system.
+// phase 0: after the residual (and setup) kernels; phase 1..4: after the m-th newton_iter_kernel of the round
+__global__ void round_newton_ctl_kernel(RoundArgs a, int phase) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.f.batch || !a.in_newton[b]) return;
+    idactl::SysCore s = a.sys[b];
+    const int n = a.v.n;
+    if (phase == 0) {
+        s.nre += 1;  // sys(y0)
+        bool go = true;
+        if (a.skipL[b] == 0) {
+            idactl::after_lsetup(s, a.lu_info[b]);
+            if (s.nls_ret == idactl::NLS_LSETUP_RECVR) {
+                s.nconvfails += 1;  // jcur is true: no retry (newton.rs:146-153 with Q3)
+                go = false;
+            }
+        }
+        if (go) {
+            s.curiter = 0;
+            a.skipI[b] = 0;
+            a.scale[b] = s.cjratio != 1.0 ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:406-410
+        }
+    } else {
+        if (a.skipI[b] != 0) return;
+        a.skipS[b] = 1;
+        atomicAdd(&a.stats[IDAHIP_K_NEWTON_ITER], 1ull);
+        const double delnrm = sqrt(a.nrm_out[b] / (double)n);
+        s.niters += 1;
+        bool converged = false;
+        int ret = idactl::conv_test(s, delnrm, &converged);
+        if (ret == idactl::NLS_SUCCESS && converged) {
+            s.jcur = false;
+            s.nls_ret = idactl::NLS_SUCCESS;
+            a.skipI[b] = 1;
+        } else {
+            if (ret == idactl::NLS_SUCCESS) {
+                s.curiter += 1;
+                if (s.curiter >= idactl::MAXNLSIT) ret = idactl::NLS_CONV_RECVR;
+            }
+            if (ret == idactl::NLS_SUCCESS) {
+                a.skipS[b] = 0;  // sys(y), then iterate again
+                s.nre += 1;
+                atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
+            } else {
+                s.nconvfails += 1;  // ConvergenceRecover
+                a.skipI[b] = 1;
+                if (!s.jcur) {
+                    s.call_lsetup = true;
+                    s.newton_retry = true;  // sys(y0) + setup + iterations again: in the next round
+                } else {
+                    s.nls_ret = idactl::NLS_CONV_RECVR;
+                }
+            }
+        }
+    }
+    a.sys[b] = s;
+}
+
+// ---- end of a round: the rest of the attempt, the schedule, Ida::new again when streaming, the round's summary
+__global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
+    extern __shared__ __align__(16) double sm[];
+    const int b = blockIdx.x;
+    idactl::SysCore s = a.sys[b];
+    WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
+    const IdaFlow<WgVec> F{a.f, s, v};
+    bool stepping = a.stepping[b] != 0;
+    if (stepping && a.in_newton[b] && !s.newton_retry) stepping = F.attempt_end();
+    const long long ground = a.round_base + a.round + 1;
+    if (a.f.recycle) stepping = F.after_round_stream(stepping, ground, b, threadIdx.x == 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.sys[b] = s;
+        a.stepping[b] = stepping ? 1 : 0;
+        if (stepping) atomicAdd(&a.summary[0], 1);
+        else if (s.status < 0 && a.in_newton[b]) atomicAdd(&a.summary[1], 1);
+    }
+}
+
+__global__ void round_init_kernel(RoundArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.f.batch) return;
+    a.ident[b] = b;
+    a.stepping[b] = 0;
+    a.rounds_done[b] = 0;
+}
+
+}  // namespace idahip
