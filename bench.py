@@ -23,11 +23,11 @@ What is timed.
   kernel_classes_rank0, roofline, lu_plus_solve
                measured in further, untimed repetitions of the K steps with HIP-event timers on the ctx stream: once per
                kernel class, once per kernel of the LU (the dominant kernel's `roofline`).
-  fast_vs_exact  (N = 1 only) one more whole pass with the FMA-contracted LU (idahip_set_lu_variant(5)): its rate, its
-               LU + solve figure, and the number of systems whose nst / netf / ncfn / nni / nsetups / kused differ from the
-               exact pass. `value` is always measured with the exact LU.
+  device_controller, newton_fusion  (N = 1 only) the whole pass again with the lock-step HOST stepper (idaens_set_device_controller(0))
+               and, on top of that, with one host round trip per Newton iteration: the before/after of moving the controller to the
+               device. Same work, same results.
 Multi-GPU (config 5): the ensemble shards embarrassingly -- rank r integrates systems [4096 r, 4096 (r+1)); no data-path
-collective; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the time.
+collective; the ranks meet over gloo on CPU tensors for the barrier and the max-over-ranks of the time (no RCCL).
 """
 import argparse
 import json
@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--workload", choices=tuple(WORKLOADS), default="linear_dense",
                     help="linear_dense = config 3 (the headline, N=512 B=4096); heat1d = config 4 (N=4096 B=256); lorenz63 = config 2 (N=3 B=1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip whole_pass and fast_vs_exact (N = 1 extras)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the whole-pass figures (N = 1 extras)")
     args = ap.parse_args()
     dn, db = {"linear_dense": (512, 4096), "heat1d": (4096, 256), "lorenz63": (3, 1024)}[args.workload]
     args.n = dn if args.n is None else args.n
@@ -382,10 +382,7 @@ def main():
         rates = [p["iters"] / p["seconds"] for p in passes]
         # the same passes with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
         # device-side convergence tests (first slice); identical work and results, only the pace changes
-        unfused_rates = [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, fused=0)) for _ in range(3)]
-        fast = run.whole_pass(5, level=1)
-        differ = int((fast["counts"] != passes[0]["counts"]).any(axis=0).sum())
-        rel = float(np.abs(fast["yy"] - passes[0]["yy"]).max() / max(1e-300, np.abs(passes[0]["yy"]).max()))
+        unfused_rates = [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, fused=0, device_ctl=0)) for _ in range(3)]
         extras = {
             "whole_pass": {"value": statistics.median(rates), "unit": "Newton iters/s", "passes": [round(r, 1) for r in rates],
                            "newton_iters_per_pass": passes[0]["iters"], "rounds_per_pass": passes[0]["rounds"],
@@ -393,23 +390,16 @@ def main():
                            "protocol": "SURVEY 8(d): every system from fresh state through its whole output schedule, exact LU, "
                                        "median of 3 passes, wall time of the pass with inputs resident"},
             "newton_fusion": {"whole_pass_value_with_host_ctest_every_iteration": statistics.median(unfused_rates), "unit": "Newton iters/s",
-                              "note": "`value` and `whole_pass` run with idahip_newton_iter2 (first two Newton iterations and their "
-                                      "convergence tests in one device call); this is the whole pass with one host round trip per "
-                                      "iteration instead: same work, same results, median of 3 passes"},
-            "device_controller": None if args.n > 8 else {
+                              "note": "host stepper with one host round trip per Newton iteration (idaens_set_fused_newton(0) on top of "
+                                      "idaens_set_device_controller(0)): round 1's control flow; same work, same results, median of 3 passes"},
+            "device_controller": {
                 "whole_pass_value_with_the_host_stepper": statistics.median(
                     [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, device_ctl=0)) for _ in range(3)]),
                 "unit": "Newton iters/s",
-                "note": "`value` and `whole_pass` run with the device-resident stepper (idahip_tiny_solve: the whole of Ida::solve in one "
-                        "launch, step-size and order controller on the device with a pow that has glibc's bits); this is the whole pass "
-                        "with the lock-step host stepper instead (idaens_set_device_controller(0)): same work, same results"},
-            "fast_vs_exact": {"fast_whole_pass_value": fast["iters"] / fast["seconds"], "unit": "Newton iters/s",
-                              "systems": int(passes[0]["counts"].shape[1]), "systems_with_different_counts": differ,
-                              "counts_compared": ["nst", "netf", "ncfn", "nni", "nsetups", "kused"],
-                              "max_rel_state_difference": rel,
-                              "lu_plus_solve_fast": lu_plus_solve(fast["tim"], args.n, "fma", dense=args.workload != "heat1d"),
-                              "note": "fast = idahip_set_lu_variant(5): the LU's updates contracted into FMAs; tolerance stated "
-                                      "and checked in tests/test_gpu_fastlu.py; `value` is measured with the exact LU"},
+                "note": "`value` and `whole_pass` run with the step-size and order controller on the device (n <= 8: idahip_tiny_solve, "
+                        "the whole of Ida::solve in one launch; larger n: idahip_round_solve, lock-step rounds enqueued without a host "
+                        "round trip inside a round), pow with glibc's bits; this is the whole pass with the lock-step host stepper "
+                        "instead (idaens_set_device_controller(0)): same work, same results"},
         }
 
     if rank == 0:

@@ -227,7 +227,7 @@ impl Ctx {
         Ok(())
     }
 
-    /// 4 = exact (default, bit-identical to dense_get_rf), 5 = FMA-contracted `fast` LU, 3 = exact cross-check pipeline.
+    /// 4 = default, 3 = cross-check pipeline; both bit-identical to dense_get_rf.
     pub fn set_lu_variant(&mut self, variant: i32) -> Result<(), Error> {
         let rc = unsafe { sys::idahip_set_lu_variant(self.raw, variant) };
         self.check(rc).map(|_| ())

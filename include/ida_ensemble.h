@@ -55,10 +55,16 @@ int idaens_set_max_ord(idaens* e, int maxord);          /* 1..5, default 5 */
  * convergence tests in one device call (idahip_newton_iter2) instead of one host round trip per iteration. Results are
  * identical either way; the switch exists for measurements. */
 int idaens_set_fused_newton(idaens* e, int on);
-/* on (default): for small systems with a device residual (n <= 8: Roberts, Lorenz63; IDA_NORMAL, no root functions, no trace)
- * a solve / solve_schedule / stream call is ONE device launch in which every system runs its own time loop with the
- * step-size and order controller on the device (idahip_tiny_solve); off: the lock-step host stepper for
- * every problem. Same results either way (same controller source, pow with glibc's bits); the switch is the A/B. */
+/* on (default): the step-size and order controller runs on the device where a device stepper exists
+ * (IDA_NORMAL, no root functions, no trace):
+ *   - small systems (n <= 8: Roberts, Lorenz63): a solve / solve_schedule / stream call is ONE launch in which every system
+ *     runs its own time loop (idahip_tiny_solve);
+ *   - linear dense problems with 8 < n <= 512: lock-step rounds as below, but enqueued without a host round trip inside a
+ *     round -- one synchronisation per round, none in idaens_stream (idahip_round_solve). A Newton solve that has to start
+ *     over with a fresh Jacobian does so in the next round, so a system may need one round more than with the host stepper;
+ *     its steps, orders, counters and results are the same.
+ * off: the lock-step host stepper for every problem. Same results either way (one controller source, pow with glibc's
+ * bits); the switch is the A/B. */
 int idaens_set_device_controller(idaens* e, int on);
 /* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
  * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call

@@ -201,17 +201,23 @@ typedef struct idahip_tiny_call {
 int idahip_tiny_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
                       double* hYout, double* hYPout);
 int idahip_pow_batch(idahip_ctx* ctx, const double* hX, const double* hY, double* hOut, size_t count);
+/* The same call for larger systems (8 < n <= 512, IDAHIP_LINEAR_DENSE, LU variant 4) as LOCK-STEP ROUNDS driven from the
+ * device side: a round = one step attempt of every stepping system (Ida::step's attempt loop body, src/lib.rs:613-711, with
+ * Newton::solve, crates/nonlinear/src/newton.rs:51-167, and the batched kernels of this library inside), the controller
+ * state of every system and the index lists live on the device, the host only enqueues each round's fixed launch sequence:
+ * one synchronisation per round (to learn whether any system still steps), none at all when `recycle` is set (throughput
+ * mode runs exactly max_rounds rounds). Arguments as idahip_tiny_solve; rounds_run: rounds executed by this call. */
+int idahip_round_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
+                       double* hYout, double* hYPout, int64_t* rounds_run);
 
-/* LU implementation choice. All variants factor in 64-column super-panels with a rank-64 trailing
- * update in wave-private 16-row strips and differ in how a super-panel is factored:
- *   4 = default, bit-identical to dense_get_rf: one wavefront per matrix factors the whole super-panel (<= 512 live rows);
- *   5 = `fast`: variant 4 with every update a(i,j) -= a_kj * a_ik contracted into one FMA (dense.rs:151 is a multiply then a
- *       subtract): same pivots unless two candidates differ by less than the contraction error, factors equal to within
- *       the usual backward error bound -- NOT bit-identical (tests/test_gpu_fastlu.py states and checks the tolerance);
- *   3 = bit-identical: two 32-column panels with two rows per lane and a narrow update between them (also what the
- *       leading super-panels of matrices with more than 512 rows use; more than 1024 rows: 8-column panels).
- * Any other value is refused. */
+/* LU implementation choice. Both variants are bit-identical to dense_get_rf; they factor in 64-column
+ * super-panels with a rank-64 trailing update in wave-private 16-row strips and differ in how a super-panel is factored:
+ *   4 = default: one wavefront per matrix factors the whole super-panel (<= 512 live rows);
+ *   3 = two 32-column panels with two rows per lane and a narrow update between them (the cross-check in the tests, and what
+ *       the leading super-panels of matrices with more than 512 rows use; more than 1024 rows: 8-column panels).
+ * Any other value is refused. (Round 2's variant 5, the same kernels with FMA-contracted updates, is gone: DESIGN.md.) */
 int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
+int idahip_lu_variant(const idahip_ctx* ctx); /* the variant in force */
 
 /* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the
  * ctx stream, and launch counters per kernel class ---- */

@@ -62,7 +62,6 @@ struct idahip_ctx {
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
-                         // 5: the same with FMA-contracted updates (`fast`, not bit-identical to the reference)
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)
@@ -331,13 +330,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// One update of the factorisation, a(i,j) -= a_kj * a_ik (dense.rs:151). FMA = false is the reference's arithmetic: the file
-// is compiled with -ffp-contract=off, so this is a multiply then a subtract. FMA = true is the contracted `fast` form.
-template <bool FMA>
-__device__ __forceinline__ double upd(double a, double u, double l) {
-    if (FMA) return __builtin_fma(-u, l, a);
-    return a - u * l;  // -ffp-contract=off: mul then sub (dense.rs:151)
-}
+// One update of the factorisation, a(i,j) -= a_kj * a_ik (dense.rs:151): the file is compiled with -ffp-contract=off, so this is
+// a multiply then a subtract -- the reference's arithmetic. (Round 2 also carried an FMA-contracted `fast` variant of the LU: it
+// was 13 % faster -- the trailing update is bound by LDS operand delivery, not by the arithmetic --, changed the step sequence of
+// one system in nine, and was removed in round 3.)
+__device__ __forceinline__ double upd(double a, double u, double l) { return a - u * l; }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     const int lo = __shfl_xor(__double2loint(v), mask);

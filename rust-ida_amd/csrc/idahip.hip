@@ -1042,7 +1042,7 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     if (!hSys || !call || !hRoundsDone || !hAcc || !rounds_run || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
     if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
     if (c->n <= TINY_N || c->n > WP_MAX_ROWS || c->kind != IDAHIP_LINEAR_DENSE || c->lu_variant < 4)
-        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4 or 5)", TINY_N, WP_MAX_ROWS);
+        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4)", TINY_N, WP_MAX_ROWS);
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;
@@ -1157,7 +1157,7 @@ int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
     DevGuard dev_guard__(c);
-    if (!c || variant < 3 || variant > 5) return -1;  // 3: panel + narrow update kernels, 4: wave-per-matrix panel (default), 5: 4 with FMA
+    if (!c || variant < 3 || variant > 4) return -1;  // 3: panel + narrow update kernels, 4: wave-per-matrix panel (default)
     c->lu_variant = variant;
     return 0;
 }

@@ -34,7 +34,6 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
         hipLaunchKernelGGL((lu_panel2_kernel<NB, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0, lbase);
     };
-    const bool fast = c->lu_variant == 5 && n <= LU_MAX_N;  // FMA-contracted updates (not bit-identical to the reference)
     for (int k0 = 0; k0 < n; k0 += 64) {
         if (n - k0 > LU_MAX_N) {
             // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
@@ -54,26 +53,21 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp); the second launch finishes
             // the few systems whose matrices have exact zeros or special values (it returns at once for the others)
             const int ns = (n - k0 + 63) / 64;
-#define IDAHIP_WP_LAUNCH(F, NSV) \
-    hipLaunchKernelGGL((lu_wavepanel_kernel<F, false, NSV>), dim3(nsys), dim3(64), 0, c->stream, w, k0)
-#define IDAHIP_WP_SWITCH(F)                                                                                   \
+#define IDAHIP_WP_LAUNCH(NSV) \
+    hipLaunchKernelGGL((lu_wavepanel_kernel<false, NSV>), dim3(nsys), dim3(64), 0, c->stream, w, k0)
+#define IDAHIP_WP_SWITCH()                                                                                    \
     switch (ns) {                                                                                              \
-        case 1: IDAHIP_WP_LAUNCH(F, 1); break;                                                                 \
-        case 2: IDAHIP_WP_LAUNCH(F, 2); break;                                                                 \
-        case 3: IDAHIP_WP_LAUNCH(F, 3); break;                                                                 \
-        case 4: IDAHIP_WP_LAUNCH(F, 4); break;                                                                 \
-        case 5: IDAHIP_WP_LAUNCH(F, 5); break;                                                                 \
-        case 6: IDAHIP_WP_LAUNCH(F, 6); break;                                                                 \
-        case 7: IDAHIP_WP_LAUNCH(F, 7); break;                                                                 \
-        default: IDAHIP_WP_LAUNCH(F, 8); break;                                                                \
+        case 1: IDAHIP_WP_LAUNCH(1); break;                                                                 \
+        case 2: IDAHIP_WP_LAUNCH(2); break;                                                                 \
+        case 3: IDAHIP_WP_LAUNCH(3); break;                                                                 \
+        case 4: IDAHIP_WP_LAUNCH(4); break;                                                                 \
+        case 5: IDAHIP_WP_LAUNCH(5); break;                                                                 \
+        case 6: IDAHIP_WP_LAUNCH(6); break;                                                                 \
+        case 7: IDAHIP_WP_LAUNCH(7); break;                                                                 \
+        default: IDAHIP_WP_LAUNCH(8); break;                                                                \
     }
-            if (fast) {
-                IDAHIP_WP_SWITCH(true)
-                hipLaunchKernelGGL((lu_wavepanel_kernel<true, true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-            } else {
-                IDAHIP_WP_SWITCH(false)
-                hipLaunchKernelGGL((lu_wavepanel_kernel<false, true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
-            }
+            IDAHIP_WP_SWITCH()
+            hipLaunchKernelGGL((lu_wavepanel_kernel<true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
 #undef IDAHIP_WP_SWITCH
 #undef IDAHIP_WP_LAUNCH
         } else {
@@ -93,8 +87,6 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             const int ncb = (ntrail + 63) / 64;
             if (n > LU_MAX_N)
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-            else if (fast)
-                hipLaunchKernelGGL((lu_trail64w_kernel<LU_MAX_N, true>), dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
             else
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
         }

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 //      stored in LDS with the lane's four rows / four columns adjacent, so a k-step is four ds_read_b128 for 32 VALU
 //      ops; two k-chunks of 32 through the strip buffer, the next strip's operands in flight behind the second chunk.
 //      49 KB of LDS per workgroup -> three workgroups per CU.
-template <int MAXROWS, bool FMA = false>
+template <int MAXROWS>
 __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
     constexpr int NB = 64, KC = 32;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -886,12 +886,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             if (__ballot(z) == 0ull) {
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
-                    if (k > kk) u[k] = upd<FMA>(u[k], ukk, Ls[kk][R0 + k]);  // a(i,j) -= a_kj * a_ik, ascending kk
+                    if (k > kk) u[k] = upd(u[k], ukk, Ls[kk][R0 + k]);  // a(i,j) -= a_kj * a_ik, ascending kk
             } else {
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
                     if (k > kk) {
-                        const double tn = upd<FMA>(u[k], ukk, Ls[kk][R0 + k]);
+                        const double tn = upd(u[k], ukk, Ls[kk][R0 + k]);
                         u[k] = z ? u[k] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
                     }
             }
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             for (int kk = 0; kk < KC; ++kk) {
                 const double ut = Us[kk][pl];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = upd<FMA>(v[i], ut, Ls[kk][KC + wave * 8 + i]);
+                for (int i = 0; i < 8; ++i) v[i] = upd(v[i], ut, Ls[kk][KC + wave * 8 + i]);
             }
         } else {
 #pragma unroll 4
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
                 const double ut = Us[kk][pl];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const double tn = upd<FMA>(v[i], ut, Ls[kk][KC + wave * 8 + i]);
+                    const double tn = upd(v[i], ut, Ls[kk][KC + wave * 8 + i]);
                     v[i] = (ut != 0.0) ? tn : v[i];
                 }
             }
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) c[i][j] = upd<FMA>(c[i][j], uv[j], lv[i]);  // dense.rs:151
+                    for (int i = 0; i < 4; ++i) c[i][j] = upd(c[i][j], uv[j], lv[i]);  // dense.rs:151
             };
 #ifndef IDAHIP_TRAIL_PIPE
 #define IDAHIP_TRAIL_PIPE 1
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const double tn = upd<FMA>(c[i][j], uv[j], lv[i]);
+                        const double tn = upd(c[i][j], uv[j], lv[i]);
                         c[i][j] = (uv[j] != 0.0) ? tn : c[i][j];  // dense.rs:148
                     }
             }

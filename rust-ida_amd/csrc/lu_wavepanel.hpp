@@ -56,7 +56,7 @@ __device__ __forceinline__ double opaque_vgpr(double u) {
 // NS > 0: the number of slots (= ceil(live rows / 64)) as a compile-time constant -- the per-slot guards fold away and the
 // registers of the unused slots are never allocated (eight instantiations of the FAST kernel, one per super-panel of an
 // N = 512 factorisation); NS = 0: taken from the matrix size at run time (the SLOW kernel).
-template <bool FMA, bool SLOWK, int NS>
+template <bool SLOWK, int NS>
 __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void lu_wavepanel_kernel(LuWs w, const int k0) {
     constexpr int BIG = 1 << 20;  // pstep of a row that is still live
     if (w.cnt && (int)blockIdx.x >= *w.cnt) return;
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 if (SLOW) {
-                                    const double tn = upd<FMA>(x[S][j], ukv[j], l[S]);
+                                    const double tn = upd(x[S][j], ukv[j], l[S]);
                                     x[S][j] = (ukv[j] == 0.0) ? x[S][j] : tn;  // dense.rs:148: a_kj == 0 -> column untouched
                                 } else {
-                                    x[S][j] = upd<FMA>(x[S][j], uk[j], l[S]);
+                                    x[S][j] = upd(x[S][j], uk[j], l[S]);
                                 }
                             }
                         }
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(64, SLOWK ? 1 : (NS > 0 && NS <= 3 ? 4 : 2)) void l
 #pragma unroll
                         for (int j = kk + 1; j < 8; ++j) {
                             if (SLOW) {
-                                const double tn = upd<FMA>(x[S][j], uv[j], l);
+                                const double tn = upd(x[S][j], uv[j], l);
                                 x[S][j] = (uv[j] == 0.0) ? x[S][j] : tn;  // dense.rs:148
                             } else {
-                                x[S][j] = upd<FMA>(x[S][j], u[j], l);
+                                x[S][j] = upd(x[S][j], u[j], l);
                             }
                         }
                     }

@@ -852,13 +852,16 @@ int continue_schedule(idaens* e, SolveCall& C, int b) {
 
 // Small systems with a device residual: the whole call runs on the device, one thread per IVP with its own time loop and the
 // controller of ida_controller.hpp compiled for the device (idahip_tiny_solve). The host only moves the controller states.
-bool device_ctl_applies(const idaens* e, const SolveCall& C) {
+// 1 = one thread per system (idahip_tiny_solve), 2 = lock-step rounds driven from the device (idahip_round_solve), 0 = host stepper
+int device_ctl_applies(const idaens* e, const SolveCall& C) {
     const int k = idahip_kind(e->ctx);
-    return e->device_ctl && e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63) && e->nrtfn == 0 && C.itask == IDAENS_NORMAL &&
-           e->trace_sys < 0;
+    if (!e->device_ctl || e->nrtfn != 0 || C.itask != IDAENS_NORMAL || e->trace_sys >= 0) return 0;
+    if (e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63)) return 1;
+    if (e->n > 8 && e->n <= 512 && k == IDAHIP_LINEAR_DENSE && idahip_lu_variant(e->ctx) >= 4) return 2;
+    return 0;
 }
 
-int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds) {
+int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds, int mode) {
     std::vector<Sys>& S = e->sys;
     const int batch = e->batch;
     const size_t n = e->n;
@@ -890,8 +893,13 @@ int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, 
     std::vector<double> yo, ypo;
     if (C.hYout) yo.resize((size_t)C.ntout * batch * n);
     if (C.hYPout) ypo.resize((size_t)C.ntout * batch * n);
-    ENS_CALL(e, idahip_tiny_solve(e->ctx, st.data(), sizeof(SysCore), &call, rounds.data(), acc, C.hYout ? yo.data() : nullptr,
-                                  C.hYPout ? ypo.data() : nullptr));
+    int64_t rounds_run = -1;
+    if (mode == 1)
+        ENS_CALL(e, idahip_tiny_solve(e->ctx, st.data(), sizeof(SysCore), &call, rounds.data(), acc, C.hYout ? yo.data() : nullptr,
+                                      C.hYPout ? ypo.data() : nullptr));
+    else
+        ENS_CALL(e, idahip_round_solve(e->ctx, st.data(), sizeof(SysCore), &call, rounds.data(), acc, C.hYout ? yo.data() : nullptr,
+                                       C.hYPout ? ypo.data() : nullptr, &rounds_run));
     int64_t rmax = 0;
     bool unfinished = false;
     for (int b = 0; b < batch; ++b) {
@@ -914,7 +922,7 @@ int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, 
             hTret[b] = s.tret;
         }
     }
-    e->total_rounds += rmax;
+    e->total_rounds += rounds_run >= 0 ? rounds_run : rmax;
     e->retired_iters += (int64_t)acc[0];
     e->passes += (int64_t)acc[1];
     e->sched_unfinished = C.ntout > 1 && unfinished;
@@ -922,7 +930,7 @@ int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, 
 }
 
 int solve_core(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long max_rounds) {
-    if (device_ctl_applies(e, C)) return solve_core_device(e, C, hTret, hStatus, max_rounds);
+    if (const int mode = device_ctl_applies(e, C)) return solve_core_device(e, C, hTret, hStatus, max_rounds, mode);
     const double eps = std::numeric_limits<double>::epsilon();
     std::vector<Sys>& S = e->sys;
     SolList& sl = C.sl;

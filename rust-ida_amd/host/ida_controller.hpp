@@ -76,6 +76,7 @@ struct SysCore {
     double saved_t = 0.0, ck = 0.0;
     long ncf = 0, nef = 0, nstloc = 0;
     bool call_lsetup = false;
+    bool newton_retry = false;  // device lock-step stepper only: the Newton solve of the running attempt starts over (with a setup) in the next round
     int nls_ret = 0;
     double phi0nrm = 0.0;  // ||phi[0]||_wrms(ewt) for the next step's tolsf test
     bool ewt_bad = false;

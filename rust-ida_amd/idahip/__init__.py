@@ -35,7 +35,7 @@ HIP_SYMBOLS = [
     "idahip_wrms", "idahip_nls_sys", "idahip_nls_lsetup", "idahip_nls_sys_setup", "idahip_newton_iter", "idahip_newton_iter2", "idahip_init_first", "idahip_scale_phi1",
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
-    "idahip_tiny_solve", "idahip_pow_batch",
+    "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
     "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [

@@ -123,3 +123,59 @@ def test_failures_are_reported_like_the_host_stepper():
         assert np.array_equal(sd, sh) and np.array_equal(td, th)
         same(state(dev), state(host))
     assert (sd == -1).any() or (sd == 0).all()
+
+
+@pytest.mark.parametrize("n,batch", [(24, 8), (64, 24), (200, 6)])
+def test_device_lock_step_rounds_equal_host_stepper_and_oracle(n, batch):
+    """Linear dense problems, 8 < n <= 512: the rounds are enqueued from the host but decided on the device
+    (idahip_round_solve). Per system the same steps as the host stepper and the oracle; the number of rounds may differ (a
+    Newton solve that starts over with a fresh Jacobian does so in the next round)."""
+    from idahip import problems
+    prob = problems.linear_dense(n=n, batch=batch, procs=1)
+    touts = prob["touts"]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    for t in touts:
+        sd, td = dev.solve(t)
+        sh, th = host.solve(t)
+        assert (sd == 0).all() and np.array_equal(sd, sh) and np.array_equal(td, th)
+        same(state(dev), state(host))
+    ref = run_oracle(prob, touts)
+    c = dev.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(dev.yy(), ref["yy"][-1]) and np.array_equal(dev.yp(), ref["yp"][-1])
+    assert dev.total_rounds() >= host.total_rounds()
+
+
+def test_device_lock_step_schedule_outputs_resume_and_stream():
+    from idahip import problems
+    prob = problems.linear_dense(n=48, batch=20, procs=1)
+    touts = prob["touts"]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    sd, td, rd, yd, ypd = dev.solve_schedule(touts, outputs=True)
+    sh, th, rh, yh, yph = host.solve_schedule(touts, outputs=True)
+    assert (sd == 0).all() and np.array_equal(rd, rh) and np.array_equal(yd, yh) and np.array_equal(ypd, yph)
+    same(state(dev), state(host))
+    cs, sl = make(prob, 1)
+    ys = np.full_like(yd, np.nan)
+    for _ in range(1000):
+        s, t, r, yo, ypo = sl.solve_schedule(touts, max_rounds=23, outputs=True)
+        m = ~np.isnan(yo)
+        ys[m] = yo[m]
+        if (s != 99).all():
+            break
+    assert (s == 0).all() and np.array_equal(ys, yd)
+    same(state(sl), state(dev))
+    # throughput mode: same totals and states as the host stepper as long as no Newton solve had to start over
+    c2, d2 = make(prob, 1)
+    c3, h2 = make(prob, 0)
+    for k, stag in ((90, 30), (1, 0), (55, 0)):
+        pd = d2.stream(touts, k, stagger_rounds=stag)
+        ph = h2.stream(touts, k, stagger_rounds=stag)
+        assert d2.total_rounds() == h2.total_rounds()
+        if (h2.counter("nls_nconvfails") == 0).all() and h2.total_newton_iters() == d2.total_newton_iters():
+            assert pd == ph
+            same(state(d2), state(h2))
+    assert pd > 0
