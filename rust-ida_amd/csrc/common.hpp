@@ -57,7 +57,7 @@ struct idahip_ctx {
     int64_t* piv = nullptr;  // [batch][n]  reference pivots (dense.rs:118)
     int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
     // blocked-LU workspace
-    int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr;
+    int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr, *lu_nzb = nullptr, *lu_bz = nullptr;
     double* lu_l11 = nullptr;
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
@@ -75,6 +75,8 @@ struct idahip_ctx {
     int32_t* rnd_i = nullptr;   // 8 int arrays of length batch + lu_cnt[1] + summary[2]
     double* rnd_d = nullptr;    // 4 double arrays of length batch
     int32_t* rnd_host = nullptr;  // pinned: the round summary
+
+    unsigned long long* dbg_stamps = nullptr;  // timing builds only (idahip_debug_stamps)
 
     // problem data
     double* params = nullptr;  // [batch][nparam]

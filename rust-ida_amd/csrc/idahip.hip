@@ -93,6 +93,8 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     rc |= dalloc(c, &c->lu, bnn); rc |= dalloc(c, &c->piv, bn); rc |= dalloc(c, &c->perm, bn);
     rc |= dalloc(c, &c->lu_info, (size_t)batch);
     rc |= dalloc(c, &c->lu_redo, (size_t)batch);
+    rc |= dalloc(c, &c->lu_nzb, (size_t)batch);
+    if (n > LU_MAX_N) rc |= dalloc(c, &c->lu_bz, (size_t)batch * 64);
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
@@ -134,7 +136,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (!c) return 0;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
                     c->tiny_acc, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
@@ -1154,6 +1156,16 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
 }
 
 int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
+
+#ifdef IDAHIP_STAMPS
+/* timing builds: a device buffer for in-kernel time stamps (8 per workgroup of the instrumented launch) */
+void* idahip_debug_stamps(idahip_ctx* c, size_t words) {
+    if (!c) return nullptr;
+    if (!c->dbg_stamps && hipMalloc((void**)&c->dbg_stamps, words * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(c->dbg_stamps, 0, words * 8);
+    return c->dbg_stamps;
+}
+#endif
 
 int idahip_set_lu_variant(idahip_ctx* c, int variant) {
     DevGuard dev_guard__(c);

@@ -25,8 +25,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     if (d_cnt && (n > WP_MAX_ROWS || c->lu_variant < 4)) return fail(c, -3, "a device-side list length needs the wave-per-matrix pipeline (n <= %d)", WP_MAX_ROWS);
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.cnt = d_cnt; w.n = n;
-    w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo;
-    w.l11 = c->lu_l11; w.out = out; w.ostride = ostride; w.l11ld = 64;
+    w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;
+    w.l11 = c->lu_l11; w.stamps = c->dbg_stamps; w.out = out; w.ostride = ostride; w.l11ld = 64;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;
     constexpr int NB = LU_NB;
@@ -45,8 +45,14 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
                 hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
                 if (k0 + lb + NBS < cend)
-                    hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
-                                       cend, lb * 65);
+                {
+                    // one column block per matrix: the row tiles are dealt to several workgroups (a launch of one workgroup per
+                    // matrix leaves most of the chip idle at the batch sizes of large n)
+                    const int ntiles = (n - (k0 + lb) - NBS + 63) / 64;
+                    const int nsplit = ntiles >= 32 ? 8 : ntiles >= 16 ? 4 : ntiles >= 8 ? 2 : 1;
+                    hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8 * nsplit), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                                       cend, lb * 65, nsplit);
+                }
             }
         } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
             KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
@@ -77,7 +83,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             panel2(k0, 0);
             if (n - k0 > NB) {
                 const int cend = (k0 + 64 < n) ? k0 + 64 : n;
-                hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 2>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0);
+                hipLaunchKernelGGL((lu_trail_kernel<NB, LU_MAX_N, 2>), dim3(nsys8), dim3(256), 0, c->stream, w, k0, nsys, 1, cend, 0, 1);
                 panel2(k0 + NB, NB);
             }
         }
@@ -85,10 +91,21 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         if (ntrail > 0) {
             KTimer kt(c, IDAHIP_K_LU_TRAIL, nsys);
             const int ncb = (ntrail + 63) / 64;
-            if (n > LU_MAX_N)
-                hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-            else
-                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+            if (n > LU_MAX_N) {
+                // Large n, small batches: a banded matrix in dense storage (the heat equation's Jacobian) leaves one column block
+                // per matrix with work and that workgroup then walks all the live rows alone. The launch holds nsplit workgroups
+                // for each of the first column blocks; they share the rows once the first super-panel has shown (on the device, LuWs::nzb) that few
+                // blocks have work, and leave at once otherwise.
+                const int nstrips = (ntrail + 15) / 16;
+                int nsplit = nstrips >= 64 ? 8 : nstrips >= 32 ? 4 : nstrips >= 16 ? 2 : 1;
+                while (nsplit > 1 && nsys * nsplit > 512) nsplit >>= 1;  // two workgroups per CU: the helpers must not queue behind each other
+                const int nbs = nsplit > 1 ? std::min(ncb, LU_SPLIT_BLOCKS) : 0;
+                // first the column blocks whose 64 pivot rows are zero (off the band): found, and their U12 written, by a light
+                // kernel at full occupancy; the update kernel's workgroups for them leave at once
+                hipLaunchKernelGGL(lu_u12_zero_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * (ncb + (nsplit - 1) * nbs)), dim3(256), 0, c->stream, w, k0, nsys, ncb, nsplit);
+            } else
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, 1);
         }
     }
     {

@@ -28,6 +28,9 @@
 
 namespace idahip {
 
+constexpr int LU_SPLIT_BLOCKS = 2;  // lu_trail64w_kernel, n > 1024: column blocks per matrix whose live rows several workgroups may share
+constexpr int LU_SPARSE_COLS = 8;   // trailing kernels, n > 1024: at most this many non-zero columns of U12 -> the row-per-thread update
+
 struct LuWs {
     double* mats;      // work matrices (physical row order), column-major n x n
     long mstride;      // elements between consecutive systems
@@ -41,9 +44,12 @@ struct LuWs {
     long long* piv;    // [batch][n] reference pivots (position chosen at step k)
     long pstride;      // elements between consecutive systems in piv
     int* info;         // [batch]   0 | 1-based zero-pivot column
+    int* nzb;          // [batch]   lu_trail64w_kernel, n > 1024: column blocks of the first super-panel's update that had work
+    int* bz;           // [batch][64] n > 1024: per column block of the current super-panel's update, 1 = its pivot rows have a non-zero entry
     int* redo;         // [batch]   lu_wavepanel_kernel: 0 | 1 + first 8-column block of the super-panel left to its SLOW launch
     double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
     int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
+    unsigned long long* stamps;  // timing builds (-DIDAHIP_STAMPS): time stamps of one launch, null otherwise
     double* out;       // factors in the reference layout (rows at their pivoted positions), column-major n x n
     long ostride;      // elements between consecutive systems in out
 };
@@ -56,7 +62,32 @@ __global__ void lu_init_kernel(LuWs w) {
         w.pos[(long)b * w.n + i] = i;
         w.live[(long)b * w.n + i] = i;
     }
-    if (threadIdx.x == 0) w.info[b] = 0;
+    if (threadIdx.x == 0) {
+        w.info[b] = 0;
+        w.nzb[b] = 0;
+    }
+}
+
+// A wave-uniform value as a per-lane value the optimiser cannot see through: `u == 0 ? a : b` then stays a pair of
+// v_cndmask instead of becoming a scalar branch around the update (a branch around 64 panel registers makes the
+// register allocator keep two copies of them).
+__device__ __forceinline__ double opaque_vgpr(double u) {
+    asm volatile("" : "+v"(u));
+    return u;
+}
+
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, soffset, 0);
+    return __hiloint2double((int)r.y, (int)r.x);
+}
+
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset, double v) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u d;
+    d.x = (unsigned)__double2loint(v);
+    d.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)voffset, soffset, 0);
 }
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not drain the vector-memory counter, so global stores issued
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, in
 // R = 8 a 512-thread workgroup factors a panel of up to 4096 rows (R * NB * 2 = 128 VGPRs of panel entries). Used for the
 // leading super-panels of matrices with more than 1024 rows; the two-row kernel takes over below that.
 template <int NB, int R, int MAXT, int WPE>
-__global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, int lbase) {
+__global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, int lbase) {
     constexpr int NW = MAXT / 64;
     constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
     static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
@@ -317,6 +348,7 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
     int* __restrict__ prow = w.prow + (long)b * n;
     long long* __restrict__ piv = w.piv + (long)b * w.pstride;
     double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, n * n * 8, 0x00020000);
 
     const int m = n - k0;
     const int wd = m < NB ? m : NB;
@@ -327,67 +359,83 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
     __shared__ __align__(16) double s_row[2][NW][LDR];
     __shared__ unsigned s_kh[2][16], s_kl[2][16];
     __shared__ __align__(16) int s_p[2][16];
-    __shared__ unsigned long long s_zm[2][NW];
     __shared__ int s_r[2][NW];
     __shared__ int s_cnt[R][NW];
 
+#ifdef IDAHIP_STAMPS
+    unsigned long long* st = (k0 == 0 && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#define STAMP(i) do { if (st && t == 0) st[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    STAMP(0);
     if (t < 32) {  // slots of waves that do not exist in this launch never win
         (&s_kh[0][0])[t] = 0u;
         (&s_kl[0][0])[t] = 0u;
         (&s_p[0][0])[t] = 0x7fffffff;
     }
     bool valid[R], alive[R];
-    int r[R], mypos[R], ownk[R];
+    int r[R], mypos[R];
     double a[R][NB];
+    // The lane's R rows of the panel stay in registers for the whole kernel, column j of the panel in a[.][j]: step k turns
+    // a[.][k] of the live rows into multipliers and updates the columns right of it, so nothing is written to the matrix
+    // inside the step loop except the pivot row (from its LDS copy); the multipliers leave in one burst after the last step.
+    // (The first version rotated the columns and stored each step's multipliers at once: with the panel registers at the
+    // limit the row offsets were spilled, and every reload waited (vmcnt(0)) for the store before it -- R write round trips
+    // per step, 11 us of a 14 us step at 4096 live rows; tools/stamps_panelr.py.)
+    // Every load is unconditional (indices clamped, results masked afterwards): a guarded load makes the compiler wait for
+    // each one before it issues the next, and the R * NB column segments then arrive one round trip at a time.
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int li = t + i * T;
         valid[i] = li < m;
         alive[i] = valid[i];
-        ownk[i] = -1;
-        r[i] = valid[i] ? live[li] : 0;
-        mypos[i] = valid[i] ? pos[r[i]] : 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) a[i][j] = (valid[i] && j < wd) ? A[(long)(k0 + j) * n + r[i]] : 0.0;
+        r[i] = live[valid[i] ? li : m - 1];
     }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        mypos[i] = pos[r[i]];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[i][j] = buf_load_f64(rsrc, (unsigned)r[i] * 8u, (k0 + (j < wd ? j : wd - 1)) * n * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (!valid[i]) {
+            r[i] = 0;
+            mypos[i] = 0x7fffffff;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[i][j] = (valid[i] && j < wd) ? a[i][j] : 0.0;
+    }
+    STAMP(1);
     __syncthreads();
 
     bool failed = false;
-    auto step = [&](const int k) -> bool {
+    auto step = [&](const int k) -> bool {  // k is a compile-time constant after unrolling
         const int kc = k0 + k;
         const int par = k & 1;
         // candidate key of a live row: the bit pattern of |a| with the always-clear sign bit set (0 = no candidate);
         // ties go to the lowest position; NaN only wins at position kc (dense.rs:111-117 scan semantics)
-        unsigned kh[R], kl[R];
+        // the best of the lane's own rows, one row at a time (selects, not branches)
+        int sel = 0;
+        unsigned bkh = 0u, bkl = 0u;
+        int bpos = mypos[0];
+        double a0 = a[0][k];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            kh[i] = 0u;
-            kl[i] = 0u;
-            if (alive[i]) {
-                const double v = fabs(a[i][0]);
-                kh[i] = (unsigned)__double2hiint(v) | 0x80000000u;
-                kl[i] = (unsigned)__double2loint(v);
-                if (v != v) {
-                    kh[i] = (mypos[i] == kc) ? 0xfff00000u : 0u;
-                    kl[i] = 0u;
-                }
-            }
-        }
-        // the best of the lane's own rows
-        int sel = 0;
-        unsigned bkh = kh[0], bkl = kl[0];
-        int bpos = mypos[0];
-        double a0 = a[0][0];
-#pragma unroll
-        for (int i = 1; i < R; ++i) {
-            const bool better = kh[i] > bkh || (kh[i] == bkh && (kl[i] > bkl || (kl[i] == bkl && mypos[i] < bpos)));
-            if (better) {
-                sel = i;
-                bkh = kh[i];
-                bkl = kl[i];
-                bpos = mypos[i];
-                a0 = a[i][0];
-            }
+            const double v = fabs(a[i][k]);
+            const bool isnan_ = v != v;
+            unsigned kh = (unsigned)__double2hiint(v) | 0x80000000u, kl = (unsigned)__double2loint(v);
+            kh = isnan_ ? ((mypos[i] == kc) ? 0xfff00000u : 0u) : kh;
+            kl = isnan_ ? 0u : kl;
+            kh = alive[i] ? kh : 0u;
+            kl = alive[i] ? kl : 0u;
+            const bool better = i == 0 || kh > bkh || (kh == bkh && (kl > bkl || (kl == bkl && mypos[i] < bpos)));
+            sel = better ? i : sel;
+            bkh = better ? kh : bkh;
+            bkl = better ? kl : bkl;
+            bpos = better ? mypos[i] : bpos;
+            a0 = better ? a[i][k] : a0;
         }
         const double myrecip = 1.0 / a0;  // mult = a(k,k).recip() (dense.rs:134), off the critical path
         const unsigned mh = wave_max_u32<false>(bkh);
@@ -395,11 +443,12 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
         const bool top = bkh != 0u && bkh == mh && bkl == ml;
         const int pm = wave_min_i32f<false>(top ? bpos : 0x7fffffff);
         const bool cand = top && bpos == pm;  // this wave's candidate row (one lane, or none)
+        const int jb = k & ~1;                // row slots are written in aligned pairs
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             if (cand && sel == i) {
 #pragma unroll
-                for (int j = 0; j < NB; j += 2) {
+                for (int j = jb; j < NB; j += 2) {
                     double2 q;
                     q.x = a[i][j];
                     q.y = a[i][j + 1];
@@ -409,15 +458,10 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
             }
         }
         if (cand) s_row[par][wave][NB] = myrecip;
-        {   // zero mask of the candidate row (dense.rs:148): one entry per lane, one ballot
-            const double e = (lane < NB) ? s_row[par][wave][lane] : 1.0;
-            const unsigned long long zm = __ballot(lane > 0 && lane < NB && e == 0.0);
-            if (lane == 0) {
-                s_zm[par][wave] = zm;
-                s_kh[par][wave] = mh;  // 0 when the wave has no live row
-                s_kl[par][wave] = ml;
-                s_p[par][wave] = pm;
-            }
+        if (lane == 0) {
+            s_kh[par][wave] = mh;  // 0 when the wave has no live row
+            s_kl[par][wave] = ml;
+            s_p[par][wave] = pm;
         }
         lds_barrier();
         int bp, bw;
@@ -431,88 +475,98 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
             bp = kmin >> 4;
             bw = kmin & 15;
         }
-        const double pk = s_row[par][bw][0];
+        const double pk = s_row[par][bw][k];
         if (pk == 0.0) {  // zero pivot: Err(k+1)  (dense.rs:120-122)
             if (t == 0) w.info[b] = kc + 1;
             return false;
         }
         if (t == 0) piv[kc] = (long long)bp;
+        {
+            bool anyp = false;
+            int pr_mine = 0;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            if (alive[i] && mypos[i] == bp) {  // this row is the pivot
-                prow[kc] = r[i];
-                ownk[i] = k;
-                alive[i] = false;
-                mypos[i] = kc;
-            } else if (alive[i] && mypos[i] == kc) {
-                mypos[i] = bp;  // the row that sat at position k moves to the pivot's old position
+            for (int i = 0; i < R; ++i) {
+                const bool isp = alive[i] && mypos[i] == bp;           // this row is the pivot
+                const bool mv = alive[i] && !isp && mypos[i] == kc;    // the row that sat at position k moves to the pivot's old position
+                anyp = anyp || isp;
+                pr_mine = isp ? r[i] : pr_mine;
+                mypos[i] = isp ? kc : (mv ? bp : mypos[i]);
+                alive[i] = alive[i] && !isp;
             }
+            if (anyp) prow[kc] = pr_mine;
         }
         // the pivot row is final for the panel columns: one cooperative store of pivot + U entries from the LDS copy
-        if (wave == 0 && lane < NB && k + lane < wd)
-            A[(long)(kc + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
+        if (wave == 0 && lane >= k && lane < wd)
+            A[(long)(k0 + lane) * n + s_r[par][bw]] = s_row[par][bw][lane];
         const double recip = s_row[par][bw][NB];
-        double aik[R];
+        // the pivot row right of the pivot, and which of its entries are zero (dense.rs:148 skips those columns): the test is
+        // made on a per-lane copy the optimiser cannot see through, so the skip stays a pair of v_cndmask per entry -- a
+        // uniform branch around the 2 R NB panel registers makes the register allocator keep two copies of them and spill
+        double u[NB];
+        bool uz[NB];
+#pragma unroll
+        for (int j = jb; j < NB; j += 2) {
+            const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][j]);
+            u[j] = opaque_vgpr(q.x);
+            u[j + 1] = opaque_vgpr(q.y);
+            uz[j] = u[j] == 0.0;
+            uz[j + 1] = u[j + 1] == 0.0;
+        }
+        // multipliers (kept in a[.][k]) and the updates right of column k. The arithmetic runs on every lane: a row that is a
+        // pivot already only overwrites entries that were stored when it was chosen (columns >= its own step) and are not
+        // read again; its multipliers sit left of that and are not touched.
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            aik[i] = a[i][0] * recip;
-            if (alive[i]) A[(long)kc * n + r[i]] = aik[i];  // the multiplier is final (coalesced column store)
+            const double aik = a[i][k] * recip;  // dense.rs:134-137
+            a[i][k] = aik;
+#pragma unroll
+            for (int j = k + 1; j < NB; ++j) a[i][j] = uz[j] ? a[i][j] : a[i][j] - u[j] * aik;  // dense.rs:148-151
         }
-        const unsigned long long zmv = s_zm[par][bw];
-        const unsigned long long zm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zmv >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(zmv & 0xffffffffull));
-        // the arithmetic runs on every lane (rows that are not live compute values nobody reads)
-        if (zm == 0ull) {
-#pragma unroll
-            for (int jc = 0; jc < NB; jc += 8) {
-                double u[8];
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const double2 q = *reinterpret_cast<const double2*>(&s_row[par][bw][jc + j]);
-                    u[j] = q.x;
-                    u[j + 1] = q.y;
-                }
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (jc + j >= 1) a[i][jc + j - 1] = a[i][jc + j] - u[j] * aik[i];  // dense.rs:151, rotated one column
-            }
-        } else {
-#pragma unroll
-            for (int j = 1; j < NB; ++j) {
-                const double uj = s_row[par][bw][j];
-#pragma unroll
-                for (int i = 0; i < R; ++i) a[i][j - 1] = ((zm >> j) & 1ull) ? a[i][j] : a[i][j] - uj * aik[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) a[i][NB - 1] = 0.0;
+#ifdef IDAHIP_STAMPS
+        if (k < 4) STAMP(4 + k);
+#endif
         return true;
     };
-#pragma unroll 1
-    for (int k = 0; k < wd; ++k)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (k >= wd) break;
         if (!step(k)) { failed = true; break; }
+    }
+    STAMP(2);
     if (failed) return;
 
-    // positions, transposed L11 (multipliers of the pivot rows, read back from the matrix) and the compacted live list
+    // multipliers: a live row has one in every panel column, a pivot row in the columns left of its own step
+    // (its position is its pivot column, so that step is mypos - k0)
+    int lim[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) lim[i] = !valid[i] ? 0 : alive[i] ? wd : mypos[i] - k0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (j < lim[i]) buf_store_f64(rsrc, (unsigned)r[i] * 8u, (k0 + j) * n * 8, a[i][j]);
+    }
+    // positions, transposed L11 (multipliers of the pivot rows: earlier panels' from the matrix, this panel's from registers)
+    // and the compacted live list
 #pragma unroll
     for (int i = 0; i < R; ++i)
         if (valid[i]) pos[r[i]] = mypos[i];
-    __syncthreads();  // the multipliers stored above are visible to the whole workgroup
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        if (ownk[i] >= 0) {
-            const int kq = lbase + ownk[i];  // index of this pivot row inside the enclosing super-panel
+        if (valid[i] && !alive[i]) {
+            const int kq = lbase + lim[i];  // index of this pivot row inside the enclosing super-panel
             const double* __restrict__ src = A + (long)(k0 - lbase) * n + r[i];
-            for (int j0 = 0; j0 < kq; j0 += 8) {
+            for (int j0 = 0; j0 < lbase; j0 += 8) {  // lbase is a multiple of NB
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (j0 + u < kq) ? src[(long)(j0 + u) * n] : 0.0;
+                for (int u = 0; u < 8; ++u) v[u] = (j0 + u < lbase) ? src[(long)(j0 + u) * n] : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (j0 + u < kq) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
+                    if (j0 + u < lbase) l11[(j0 + u) * w.l11ld + kq] = v[u];  // [kk][k]: a TRSM step reads a contiguous run
             }
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < lim[i]) l11[(lbase + j) * w.l11ld + kq] = a[i][j];
         }
     }
     // live list: the surviving rows of set 0 in thread order, then those of set 1 (the list stays sorted)
@@ -535,6 +589,54 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
         }
         if (alive[i]) live[mine + __popcll(bal[i] & ((1ull << lane) - 1ull))] = r[i];
     }
+    STAMP(3);
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------------ zero column blocks (n > 1024)
+// One workgroup per (matrix, block of 64 trailing columns) of a 64-column super-panel's update: gathers the block's entries
+// of the 64 pivot rows (one pivot row per lane, a column per load: pivot rows that are neighbours in memory share cache
+// lines) and, if all are zero, writes them to the factors as they are -- a_kj == 0 leaves the column untouched in the
+// triangular solve and subtracts nothing from the rows below (dense.rs:148). LuWs::bz tells lu_trail64w_kernel which blocks
+// are left. A banded matrix in dense storage (the heat equation's Jacobian) has almost only such blocks; this kernel holds
+// no LDS to speak of and few registers, so the chip is full of gathers, where the update kernel fits two workgroups per CU.
+// k0 == 0 also counts the blocks with work (LuWs::nzb: the row split of lu_trail64w_kernel).
+__global__ __launch_bounds__(256) void lu_u12_zero_kernel(LuWs w, int k0, int nsys, int ncb) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;  // same dealing as lu_trail64w_kernel
+    if (mi >= nsys) return;
+    const int b = w.idx[mi];
+    if (w.info[b] != 0) return;
+    const int n = w.n;
+    const double* __restrict__ A = w.mats + (long)b * w.mstride;
+    double* __restrict__ O = w.out + (long)b * w.ostride;
+    const int cb0 = k0 + 64 + cbi * 64;
+    const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int s_nz[4];
+    const int pr = w.prow[(long)b * n + k0 + lane];
+    double g[16];
+    bool nz = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = wave * 16 + i;
+        g[i] = A[(long)(cb0 + (cc < ncols ? cc : 0)) * n + pr];
+        nz = nz || (cc < ncols && g[i] != 0.0);
+    }
+    const bool wnz = __ballot(nz) != 0ull;
+    if (lane == 0) s_nz[wave] = wnz ? 1 : 0;
+    __syncthreads();
+    const int any = s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3];
+    if (t == 0) {
+        w.bz[b * 64 + cbi] = any;
+        if (any && k0 == 0) atomicAdd(w.nzb + b, 1);
+    }
+    if (any) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = wave * 16 + i;
+        if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = g[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ trailing (fused)
@@ -546,12 +648,15 @@ __global__ __launch_bounds__(MAXT, WPE) __global__ __launch_bounds__(MAXT, WPE) 
 // No Ubuf round trip, no per-lane operand broadcast; the matrix is touched in coalesced column segments only
 // (the pivot-row gather/scatter is the one strided access: NB x 64 elements per workgroup).
 template <int NB, int MAXROWS, int CJ>
-__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit, int l11off) {
+__global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys, int ncb, int climit, int l11off, int nsplit) {
     // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so the column blocks of one matrix are
     // given ids with equal (id & 7) and adjacent (id >> 3): they run on one XCD at about the same time and share the
     // multiplier panel L21 (read by every column block) through that XCD's L2 instead of re-reading it from HBM.
+    // nsplit > 1: the row tiles of one (matrix, column block) are dealt to nsplit workgroups -- with one column block per matrix
+    // (the narrow update inside a super-panel) a launch would otherwise be one workgroup per matrix, a fraction of the chip.
+    // Every workgroup of a split repeats the (small) pivot-row gather and U12 solve; split 0 writes U12 to the factors.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
+    const int split = slot % nsplit, cbi = (slot / nsplit) % ncb, mi = (slot / (nsplit * ncb)) * 8 + xcd;
     if (mi >= nsys) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
@@ -573,6 +678,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     __shared__ unsigned short s_live[MAXROWS];  // row indices < 65536
     __shared__ int s_anyzero;
     __shared__ unsigned s_kmask;  // slow path: bit k set = pivot row k has a non-zero entry in this column block
+    __shared__ unsigned long long s_cmask;  // slow path: bit c set = column c of the block has a non-zero entry of U12
     __shared__ int s_nz[4];       // per wave: a non-zero entry among the pivot-row entries it gathered
 
     for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
@@ -597,10 +703,12 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
         // the pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
         // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
         double* __restrict__ O = w.out + (long)b * w.ostride;
+        if (split == 0) {
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int cc = wave * 16 + i;
-            if (cc < ncols && lane < NB) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][cc];
+            for (int i = 0; i < 16; ++i) {
+                const int cc = wave * 16 + i;
+                if (cc < ncols && lane < NB) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][cc];
+            }
         }
         return;
     }
@@ -671,16 +779,23 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
             // dense.rs:148 skips the whole row update when a_kj == 0: a pivot row that is zero across this column block
             // contributes nothing here -- banded Jacobians (heat equation) have almost only such rows
             unsigned km = 0u;
+            bool cnz = false;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) km |= (__ballot(real && u[k] != 0.0) != 0ull) ? (1u << k) : 0u;
+            for (int k = 0; k < NB; ++k) {
+                const bool e = real && u[k] != 0.0;
+                cnz = cnz || e;
+                km |= (__ballot(e) != 0ull) ? (1u << k) : 0u;
+            }
+            const unsigned long long cm = __ballot(cnz);
             if (lane == 0) {
                 s_anyzero = 1;
                 s_kmask = km;
+                s_cmask = cm;
             }
         }
-        load_tile(0, lreg, creg, crow, rok);
+        load_tile(split, lreg, creg, crow, rok);
     } else {
-        load_tile(0, lreg, creg, crow, rok);  // waves 1-3: first tile in flight while wave 0 solves for U12
+        load_tile(split, lreg, creg, crow, rok);  // waves 1-3: first tile in flight while wave 0 solves for U12
     }
     __syncthreads();
     const bool slow = s_anyzero != 0;
@@ -689,7 +804,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     // the factors -- pivot k of this panel is row k0 + k of the reference layout, so a column's NB entries are one
     // contiguous store (one row per lane) instead of NB eight-byte stores into NB different sectors of the work matrix;
     // lu_finalize_kernel skips this region.
-    {
+    if (split == 0) {
         double* __restrict__ O = w.out + (long)b * w.ostride;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -699,9 +814,30 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     }
 
     if (kmask == 0u) return;  // (uniform over the workgroup) nothing to subtract anywhere in this column block
+    if (MAXROWS > 1024 && slow) {
+        // Large n, U12 nearly empty (a banded matrix): one live row per thread, only the columns and pivot rows with a
+        // non-zero entry are touched (see lu_trail64w_kernel). Same arithmetic per entry: ascending k, a_kj == 0 skipped.
+        const unsigned long long cmask = s_cmask;
+        if (__popcll(cmask) <= LU_SPARSE_COLS) {
+            for (int ri = split * 256 + t; ri < mrem; ri += 256 * nsplit) {
+                const int row = s_live[ri];
+                for (unsigned long long cmm = cmask; cmm != 0ull; cmm &= cmm - 1ull) {
+                    const int c = __builtin_ctzll(cmm);
+                    double v = A[(long)(cb0 + c) * n + row];
+                    for (unsigned mk = kmask; mk != 0u; mk &= mk - 1u) {
+                        const int kk = __builtin_ctz(mk);
+                        const double u = Us[kk][c];
+                        if (u != 0.0) v = v - u * A[(long)(k0 + kk) * n + row];
+                    }
+                    A[(long)(cb0 + c) * n + row] = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll 1
-    for (int rt = 0; rt < ntiles; ++rt) {
-        const int buf = rt & 1;
+    for (int rt = split, it = 0; rt < ntiles; rt += nsplit, ++it) {
+        const int buf = it & 1;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Ls[buf][wave * LPT + i][lane] = lreg[i];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -715,7 +851,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 #pragma unroll
             for (int j = 0; j < CJ; ++j) c[i][j] = creg[i][j];
         }
-        if (rt + 1 < ntiles) load_tile(rt + 1, lreg, creg, crow, rok);  // in flight behind the arithmetic below
+        if (rt + nsplit < ntiles) load_tile(rt + nsplit, lreg, creg, crow, rok);  // in flight behind the arithmetic below
         if (!slow) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -768,13 +904,35 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 //      ops; two k-chunks of 32 through the strip buffer, the next strip's operands in flight behind the second chunk.
 //      49 KB of LDS per workgroup -> three workgroups per CU.
 template <int MAXROWS>
-__global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb) {
+__global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb, int nsplit_arg) {
     constexpr int NB = 64, KC = 32;
+    const int nsplit = MAXROWS > 1024 ? nsplit_arg : 1;  // the row split exists for large n only
+    // workgroups of one matrix: its ncb column blocks, then (nsplit > 1) nsplit - 1 helpers for each of the first
+    // LU_SPLIT_BLOCKS column blocks
+    const int nbs = nsplit > 1 ? (ncb < LU_SPLIT_BLOCKS ? ncb : LU_SPLIT_BLOCKS) : 0;
+    const int hs = nsplit > 1 ? nsplit - 1 : 1;  // helpers per split column block
+    const int wpm = ncb + hs * nbs;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;
+    const int sm = slot % wpm, mi = (slot / wpm) * 8 + xcd;
+    const int cbi = sm < ncb ? sm : (sm - ncb) / hs;
+    const int split = sm < ncb ? 0 : 1 + (sm - ncb) % hs;
     if (mi >= (w.cnt ? ldc(w.cnt) : nsys)) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
+    // nsplit > 1: the strips of live rows of one (matrix, column block) are dealt to nsplit workgroups when the matrix has
+    // shown itself banded -- at most a quarter of the column blocks of the first super-panel's update (k0 == 0, counted in
+    // nzb by lu_u12_zero_kernel) had a non-zero pivot-row entry -- and the block is one of the first few, next to the panel, where a band has its
+    // work. Every workgroup of a split repeats the gather and the U12 solve; split 0 writes U12 to the factors. Otherwise
+    // (dense matrices: every column block has work and the launch fills the chip by itself) split 0 does it all and the
+    // helpers leave. All workgroups of a launch read the same, already final, count.
+    if (MAXROWS > 1024 && ldc(w.bz + b * 64 + cbi) == 0) return;  // zero block: lu_u12_zero_kernel has dealt with it
+    int nsp = 1;
+    if (nsplit > 1) {
+        const int nzb = ldc(w.nzb + b);
+        const bool banded = k0 > 0 && nzb * 4 <= (w.n - 1) / 64;
+        if (banded && cbi < nzb && cbi < nbs) nsp = nsplit;
+        else if (split != 0) return;
+    }
     const int n = w.n;
     double* __restrict__ A = w.mats + (long)b * w.mstride;
     const int* __restrict__ live = w.live + (long)b * n;
@@ -799,16 +957,32 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     __shared__ int s_anyzero;
     __shared__ int s_nz[4];          // per wave: a non-zero entry among the pivot-row entries it gathered
     __shared__ unsigned s_kmask[2];  // slow path: bit k of word R0 / 32 set = pivot row R0 + k has a non-zero entry in this column block
+    __shared__ unsigned long long s_cmask[2];  // slow path: bit c set = column c of the block has a non-zero entry among pivot rows R0 .. R0 + 31
 
-    for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+    if (MAXROWS <= 1024)
+        for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
     bool nz = false;
+    if (MAXROWS > 1024) {
+        // large n: one pivot row per lane, a column per load. Pivot rows that are neighbours in memory (a banded matrix that
+        // pivots little or not at all) then share cache lines -- 4 lines per load instead of 64 sectors; most workgroups of
+        // a banded matrix do nothing but this gather (their block turns out zero), and it bounds the launch.
+        const int pr = prow[lane];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            const double g = (cc < ncols) ? A[(long)(cb0 + cc) * n + pr] : 0.0;
+            nz = nz || (g != 0.0);
+            Us[lane][4 * (cc & 15) + (cc >> 4)] = g;
+        }
+    } else {
 #pragma unroll
-    for (int pass = 0; pass < NB / 4; ++pass) {
-        const int k = pass * 4 + wave;
-        const int pr = ldc(prow + k);
-        const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
-        nz = nz || (g != 0.0);
-        Us[k][pl] = g;
+        for (int pass = 0; pass < NB / 4; ++pass) {
+            const int k = pass * 4 + wave;
+            const int pr = ldc(prow + k);
+            const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+            nz = nz || (g != 0.0);
+            Us[k][pl] = g;
+        }
     }
     if (lane == 0) s_nz[wave] = 0;
     if (__ballot(nz) != 0ull && lane == 0) s_nz[wave] = 1;
@@ -820,11 +994,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
         }
     };
-    stage_l11(0);
+    if (MAXROWS <= 1024) stage_l11(0);
     lds_barrier();
     if ((s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3]) == 0) {
         // the 64 pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
         // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
+        if (split != 0) return;
         double* __restrict__ O = w.out + (long)b * w.ostride;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -833,6 +1008,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
         }
         return;
     }
+    if (MAXROWS > 1024) {  // large n: most column blocks of a banded matrix have left by now, without having read these
+        for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+        stage_l11(0);
+        lds_barrier();
+    }
+    const int s0 = wave + 4 * split, sstep = 4 * nsp;  // this wave's strips: s0, s0 + sstep, ...
 
     // ---- this lane's share of a strip: rows a + 4i, columns q + 16j
     const int a = lane & 3, q = lane >> 2;
@@ -887,6 +1068,8 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
                     if (k > kk) u[k] = upd(u[k], ukk, Ls[kk][R0 + k]);  // a(i,j) -= a_kj * a_ik, ascending kk
+            } else if (MAXROWS > 1024 && __ballot(real && !z) == 0ull) {
+                // pivot row kk is zero across the whole block (banded matrices): every column is left as it is
             } else {
 #pragma unroll
                 for (int k = 0; k < KC; ++k)
@@ -902,21 +1085,29 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
         // contributes nothing to it -- banded Jacobians (heat equation) have almost only such rows. (The mask is only read
         // on the select path, i.e. when some entry of the block is an exact zero.)
         unsigned km = 0xffffffffu;
+        unsigned long long cm = ~0ull;
         if (__ballot(anyz) != 0ull || s_anyzero != 0) {
             km = 0u;
+            bool cnz = false;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) km |= (__ballot(real && u[k] != 0.0) != 0ull) ? (1u << k) : 0u;
+            for (int k = 0; k < KC; ++k) {
+                const bool e = real && u[k] != 0.0;
+                cnz = cnz || e;
+                km |= (__ballot(e) != 0ull) ? (1u << k) : 0u;
+            }
+            cm = __ballot(cnz);
         }
         if (lane == 0) {
             s_kmask[R0 / KC] = km;
+            s_cmask[R0 / KC] = cm;
             if (__ballot(anyz) != 0ull) s_anyzero = 1;
         }
     };
 
     if (wave == 0) trsm32(0);
-    else if (wave < nstrips) {  // live rows only (untouched by the U12 stores), in flight behind the solves
-        load_C(wave);
-        load_L(wave, 0);
+    else if (s0 < nstrips) {  // live rows only (untouched by the U12 stores), in flight behind the solves
+        load_C(s0);
+        load_L(s0, 0);
     }
     lds_barrier();
     {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
@@ -935,6 +1126,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll 4
             for (int kk = 0; kk < KC; ++kk) {
                 const double ut = Us[kk][pl];
+                if (MAXROWS > 1024 && __ballot(ut != 0.0) == 0ull) continue;  // zero pivot row: nothing to subtract
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const double tn = upd(v[i], ut, Ls[kk][KC + wave * 8 + i]);
@@ -950,9 +1142,9 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     lds_barrier();
     if (wave == 0) {
         trsm32(KC);
-        if (0 < nstrips) {
-            load_C(0);
-            load_L(0, 0);
+        if (s0 < nstrips) {
+            load_C(s0);
+            load_L(s0, 0);
         }
     }
     lds_barrier();  // last workgroup barrier: from here on a wave touches only Us (read-only) and its own strip of Ls
@@ -961,7 +1153,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     // the factors -- pivot k of this super-panel is row k0 + k of the reference layout, so a column's 64 entries are one
     // contiguous 512-byte store (one row per lane) instead of 64 eight-byte stores into 64 different sectors of the work
     // matrix; lu_finalize_kernel skips this region.
-    {
+    if (split == 0) {
         double* __restrict__ O = w.out + (long)b * w.ostride;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -972,6 +1164,35 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     const unsigned kmask0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[0]);
     const unsigned kmask1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[1]);
     if (slow && (kmask0 | kmask1) == 0u) return;  // (uniform over the workgroup) U12 of this block is all zeros: nothing to subtract
+    if (MAXROWS > 1024 && slow) {
+        // Large n, U12 nearly empty (a banded matrix: a few columns next to the panel, a few pivot rows): one live row per
+        // thread, and only the columns and pivot rows that have a non-zero entry are touched -- the strips below would read
+        // and write back all 64 columns of every live row to change one of them. Same arithmetic per entry: ascending k,
+        // a_kj == 0 skipped (dense.rs:148-151).
+        const unsigned long long cmask = s_cmask[0] | s_cmask[1];
+        if (__popcll(cmask) <= LU_SPARSE_COLS) {
+            for (int ri = split * 256 + t; ri < mrem; ri += 256 * nsp) {
+                const int row = s_live[ri];
+                for (unsigned long long cmm = cmask; cmm != 0ull; cmm &= cmm - 1ull) {
+                    const int c = __builtin_ctzll(cmm);
+                    const int cs = 4 * (c & 15) + (c >> 4);
+                    double v = A[(long)(cb0 + c) * n + row];
+                    for (unsigned mk = kmask0; mk != 0u; mk &= mk - 1u) {
+                        const int kk = __builtin_ctz(mk);
+                        const double u = Us[kk][cs];
+                        if (u != 0.0) v = upd(v, u, A[(long)(k0 + kk) * n + row]);
+                    }
+                    for (unsigned mk = kmask1; mk != 0u; mk &= mk - 1u) {
+                        const int kk = KC + __builtin_ctz(mk);
+                        const double u = Us[kk][cs];
+                        if (u != 0.0) v = upd(v, u, A[(long)(k0 + kk) * n + row]);
+                    }
+                    A[(long)(cb0 + c) * n + row] = v;
+                }
+            }
+            return;
+        }
+    }
     double (*__restrict__ Lw)[16] = reinterpret_cast<double (*)[16]>(&Ls[0][0] + wave * (KC * 16));
 
     auto chunk = [&](double (&c)[4][4], const int kbase) {
@@ -1033,7 +1254,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     };
 
 #pragma unroll 1
-    for (int s = wave; s < nstrips; s += 4) {
+    for (int s = s0; s < nstrips; s += sstep) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];
         load_L(s, 1);  // the strip's second k-chunk, in flight behind the first chunk's arithmetic
@@ -1050,9 +1271,9 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
         chunk(c, 0);
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];  // same wave, program order: chunk 0's reads are done
-        if (s + 4 < nstrips) {  // next strip in flight behind the second chunk
-            load_C(s + 4);
-            load_L(s + 4, 0);
+        if (s + sstep < nstrips) {  // next strip in flight behind the second chunk
+            load_C(s + sstep);
+            load_L(s + sstep, 0);
         }
         chunk(c, KC);
 #pragma unroll

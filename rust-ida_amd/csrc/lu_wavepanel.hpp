@@ -39,20 +39,6 @@ constexpr int WP_MAX_ROWS = 512;
 // for instruction issue, not for the loads; IDAHIP_WP_RING=1 builds the deep rings for another look)
 constexpr int WP_RING(int ns) { return !IDAHIP_WP_RING ? 2 : (ns >= 1 && ns <= 2) ? 8 : (ns >= 3 && ns <= 7) ? 4 : 2; }  // 8 slots of 64 lanes
 
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, soffset, 0);
-    return __hiloint2double((int)r.y, (int)r.x);
-}
-
-// A wave-uniform value as a per-lane value the optimiser cannot see through: `u == 0 ? a : b` then stays a pair of
-// v_cndmask instead of becoming a scalar branch around the update (a branch around 64 panel registers makes the
-// register allocator keep two copies of them).
-__device__ __forceinline__ double opaque_vgpr(double u) {
-    asm volatile("" : "+v"(u));
-    return u;
-}
-
 // NS > 0: the number of slots (= ceil(live rows / 64)) as a compile-time constant -- the per-slot guards fold away and the
 // registers of the unused slots are never allocated (eight instantiations of the FAST kernel, one per super-panel of an
 // N = 512 factorisation); NS = 0: taken from the matrix size at run time (the SLOW kernel).
