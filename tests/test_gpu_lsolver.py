@@ -158,6 +158,39 @@ def test_lu_beyond_1024_rows(n):
     assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
 
 
+@pytest.mark.parametrize("n", [1536, 2120])
+def test_banded_and_partly_banded_matrices_beyond_1024_rows(n):
+    """The large-n trailing updates treat nearly empty U12 blocks apart (zero column blocks found by their own kernel, the
+    rest applied one live row per thread, helpers sharing the rows once the first super-panel has shown a band): a
+    tridiagonal matrix, a wider band that pivots, a band that turns dense after the first super-panel (helpers on the
+    dense path) and a matrix with dense leading rows (no band seen) all factor like the reference."""
+    rng = np.random.default_rng(n + 7)
+    B = 4
+    m = np.zeros((B, n, n))
+    i = np.arange(n)
+    m[0, i, i] = 4.0 + rng.random(n)
+    m[0, i[1:], i[:-1]] = -1.0 - rng.random(n - 1)
+    m[0, i[:-1], i[1:]] = -1.0 - rng.random(n - 1)
+    for d in range(-3, 4):  # band of 7, weak diagonal: partial pivoting swaps rows and widens U
+        k = np.arange(max(0, -d), min(n, n - d))
+        m[1, k, k + d] = rng.standard_normal(k.size) * (0.3 if d == 0 else 1.0)
+    m[2] = m[0]
+    m[2, 64:, 64:] = rng.standard_normal((n - 64, n - 64))  # banded where the band is measured, dense behind it
+    m[3] = m[0]
+    m[3, :40, :] = rng.standard_normal((40, n))             # dense leading rows: every column block has work
+    rhs = rng.standard_normal((B, n))
+    info_o, lu_o, piv_o = oracle_lu(m)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(m)
+    assert rc == 0 and np.array_equal(info, info_o)
+    assert np.array_equal(piv, piv_o)
+    assert np.array_equal(lu, lu_o)
+    dB = ctx.dev_array(rhs)
+    dX = ctx.dev_empty(rhs.nbytes)
+    ctx.ls_solve(dA, dP, dX, dB)
+    x_o = np.array([O.getrs(lu_o[s], piv_o[s], rhs[s]) for s in range(B)])
+    assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
+
+
 def test_pivot_ties_resolve_like_the_reference_scan():
     n = 40
     rng = np.random.default_rng(7)
