@@ -431,7 +431,7 @@ def main():
             v = tim2["lu_trail"]
             tfl = flops * mats / (v["ms"] * 1e-3) / 1e12
             tr = profiled_traffic("lu_trail64w_kernel") if (args.workload == "linear_dense" and args.n == 512) else None
-            roof = {"bound": "valu", "kernel": "lu_trail64w_kernel<%d, false> (rank-64 trailing update + U12 solve of the batched getrf)" % (1024 if args.n <= 1024 else 4096),
+            roof = {"bound": "valu", "kernel": "lu_trail64w_kernel<%d> (rank-64 trailing update + U12 solve of the batched getrf)" % (1024 if args.n <= 1024 else 4096),
                     "share_of_device_time": round(cand[dom] / total_ms, 4),
                     "achieved": round(tfl, 2), "peak": VALU_UNFUSED_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / VALU_UNFUSED_TFLOPS, 4),
                     "peak_note": "fp64 vector ceiling of the reference's arithmetic: a multiply and a subtract per update (dense.rs:151), "
