@@ -40,8 +40,8 @@ for name, c in sq.items():
     d = {kk: vv for kk, vv in c.items()}
     wc_, bc_ = c.get("SQ_WAVE_CYCLES", 0.0), c.get("SQ_BUSY_CYCLES", 0.0)
     der = {}
-    # SQ_ACTIVE_INST_* count cycles (x4 per SIMD quad on gfx9) in which a wave of that SIMD issues to the unit; fractions are of
-    # the busy cycles of the shader engines' sequencers -- see DESIGN.md section 4 for how they are read
+    # SQ_ACTIVE_INST_* advance by one per four cycles in which a SIMD issues to the unit; SQ_BUSY_CYCLES sums the busy cycles of
+    # the 32 shader engines: VALU busy per SIMD = ratio / 8, LDS busy per CU = ratio / 2 (profiles/README.md, round 3)
     if bc_ > 0:
         for cn in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY"):
             if cn in c:
