@@ -589,6 +589,9 @@ static int launch_newton_iter(idahip_ctx* c, const int* d_idx, const double* d_s
     if (n <= TINY_N) {
         hipLaunchKernelGGL(tiny_newton_iter_kernel, dim3((nsys + 63) / 64), dim3(64), 0, c->stream, (const double*)c->lu,
                            (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, d_skip);
+    } else if (n % 2 == 0 && n >= 2048) {
+        hipLaunchKernelGGL((newton_iter_kernel<2, 1024>), dim3(nsys), dim3(1024), sizeof(double) * (n + (n > 4096 ? n : 4096)), c->stream, (const double*)c->lu,
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
     } else if (n % 2 == 0) {
         hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
                            (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);

@@ -30,15 +30,38 @@ __device__ __forceinline__ double seq_sum_lds(const double* sq, int n) {
     return s;
 }
 
-// Workgroup-cooperative getrs on the right-hand side held in LDS (bs[0..n)). blockDim.x == 256.
+// Workgroup-cooperative getrs on the right-hand side held in LDS (bs[0..n)). blockDim.x == T.
 // VEC = 2 requires n even (16-byte aligned column segments).
-template <int VEC>
-__device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, double* bs) {
+// dg (T > 256 only): 64 x 64 doubles of LDS for the diagonal block. With few, large systems per call a workgroup's life is
+// its 2 n / 64 diagonal solves, and each of those was eight dependent round trips to memory (eight columns loaded, eight
+// steps, ...): 17 us per block at n = 4096. The block a solve needs is instead fetched by all threads while the sweep before
+// it streams (the factors are read-only), and the solve reads LDS.
+template <int VEC, int T = 256>
+__device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, double* bs, double* dg = nullptr) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int T = 256;
-    constexpr int UNR = 8;
+    constexpr bool STAGE = T > 256;
+    constexpr int UNR = 8;  // columns in flight per thread (16 changes nothing: a workgroup's stream is bound by its CU, ~30 GB/s)
+    constexpr int SPT = STAGE ? (64 * 64) / T : 1;  // staged entries per thread
+    double stg[SPT];
+    auto stage_load = [&](int kb) {  // diagonal block at (kb, kb): entry e = t + j T is row e & 63 of column e >> 6
+        const int kw = (n - kb) < 64 ? (n - kb) : 64;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int e = t + j * T, c = e >> 6, r = e & 63;
+            stg[j] = (c < kw && r < kw) ? LU[(long)(kb + c) * n + kb + r] : 0.0;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) dg[t + j * T] = stg[j];
+    };
+    if (STAGE) {
+        stage_load(0);
+        stage_store();
+        __syncthreads();
+    }
 
     // ---- forward: L y = b, unit diagonal (dense.rs:188-194)
 #pragma unroll 1
@@ -53,7 +76,8 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 + u;
-                    lik[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
+                    if (STAGE) lik[u] = (k + 1 < kw && lane > k && lane < kw) ? dg[k * 64 + lane] : 0.0;
+                    else lik[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -68,6 +92,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         }
         __syncthreads();
         const int ibeg = kb + 64;
+        if (STAGE && ibeg < n) stage_load(ibeg);  // the next diagonal block, in flight behind the sweep
         if (ibeg < n) {  // rows below a full 64-column block
 #pragma unroll 1
             for (int i = ibeg + VEC * t; i < n; i += VEC * T) {
@@ -100,6 +125,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                     if (i + v < n) bs[i + v] = acc[v];
             }
         }
+        if (STAGE && ibeg < n) stage_store();  // (the solve that read dg ended before the barrier above)
         __syncthreads();
     }
 
@@ -118,7 +144,8 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 - u;
-                    uik[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
+                    if (STAGE) uik[u] = (k >= 0 && lane <= k) ? dg[k * 64 + lane] : 1.0;
+                    else uik[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -133,6 +160,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
             if (lane < kw) bs[i] = bi;
         }
         __syncthreads();
+        if (STAGE && kb > 0) stage_load(kb - 64);
         if (kb > 0) {
 #pragma unroll 1
             for (int i = VEC * t; i < kb; i += VEC * T) {  // kb is a multiple of 64 (hence even): i + v < kb
@@ -168,6 +196,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 for (int v = 0; v < VEC; ++v) bs[i + v] = acc[v];
             }
         }
+        if (STAGE && kb > 0) stage_store();
         __syncthreads();
     }
 }
@@ -224,8 +253,10 @@ __global__ __launch_bounds__(256) void wrms_kernel(const double* __restrict__ X,
 
 // ------------------------------------------------------------------------------------------------ fused Newton body
 // delta = -delta; delta = LU^-1 delta; delta *= scale; ee += delta; out = sum_i (delta_i ewt_i)^2 (sequential).
-template <int VEC>
-__global__ __launch_bounds__(256, 4) void newton_iter_kernel(const double* __restrict__ LU, const int* __restrict__ perm, double* __restrict__ delta,
+// T = 1024 for n >= 2048: one workgroup per system streams 8 n^2 bytes, and with few large systems in a call (config 4: ~128
+// of 134 MB each) 256 threads per system do not keep enough loads in flight to fill the memory system.
+template <int VEC, int T = 256>
+__global__ __launch_bounds__(T, T == 256 ? 4 : 1) void newton_iter_kernel(const double* __restrict__ LU, const int* __restrict__ perm, double* __restrict__ delta,
                                                           double* __restrict__ ee, const double* __restrict__ ewt, int n,
                                                           const int* __restrict__ idx, const double* __restrict__ scale,
                                                           double* __restrict__ out, const int* __restrict__ skip) {
@@ -236,11 +267,11 @@ __global__ __launch_bounds__(256, 4) void newton_iter_kernel(const double* __res
     const int b = idx[blockIdx.x];
     const int t = threadIdx.x;
     const long vb = (long)b * n;
-    for (int i = t; i < n; i += 256) bs[i] = -delta[vb + perm[vb + i]];  // neg_mut, then the row permutation
+    for (int i = t; i < n; i += T) bs[i] = -delta[vb + perm[vb + i]];  // neg_mut, then the row permutation
     __syncthreads();
-    wg_getrs<VEC>(LU + (long)b * n * n, n, bs);
+    wg_getrs<VEC, T>(LU + (long)b * n * n, n, bs, T > 256 ? sq : nullptr);  // sq (>= 4096 doubles for T > 256) is free until the solve is done
     const double sc = scale[blockIdx.x];
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += T) {
         const double d = bs[i] * sc;  // ida_ls.rs:406-410 (sc == 1.0 exactly when cjratio == 1)
         delta[vb + i] = d;
         ee[vb + i] = ee[vb + i] + d;  // newton.rs:106
