@@ -19,6 +19,7 @@ constexpr int MXORDP1 = 6;      // src/constants.rs:6
 constexpr int TINY_N = 8;       // n <= TINY_N: one thread per system (whole Newton body in registers/L1)
 constexpr int LU_NB = 32;       // panel width of the blocked LU
 constexpr int LU_MAX_N = 1024;  // blocked LU, fast pipelines: at most two panel rows per lane of a 512-thread workgroup
+constexpr int LU_WIDE_ROWS = 2048;  // n > 1024: at most this many live rows -> 16-column panels with four rows per lane (above: 8 columns, eight rows)
 constexpr int LU_BIG_MAX_N = 4096;  // blocked LU with eight panel rows per lane for the leading super-panels
 constexpr int NSLOT = 8;
 

@@ -36,22 +36,38 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     };
     for (int k0 = 0; k0 < n; k0 += 64) {
         if (n - k0 > LU_MAX_N) {
-            // more than 1024 live rows: eight 8-column panels with eight rows per lane, each followed by its narrow
-            // update of the rest of the super-panel
+            // more than 1024 live rows: 8-column panels with eight rows per lane (16-column panels with four rows per lane
+            // once at most LU_WIDE_ROWS rows are live: half the launches), each followed by its narrow update of the rest of
+            // the super-panel
             KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
-            constexpr int NBS = 8;
             const int cend = (k0 + 64 < n) ? k0 + 64 : n;
-            const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
-            for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
-                hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
-                if (k0 + lb + NBS < cend)
-                {
-                    // one column block per matrix: the row tiles are dealt to several workgroups (a launch of one workgroup per
-                    // matrix leaves most of the chip idle at the batch sizes of large n)
-                    const int ntiles = (n - (k0 + lb) - NBS + 63) / 64;
-                    const int nsplit = ntiles >= 32 ? 8 : ntiles >= 16 ? 4 : ntiles >= 8 ? 2 : 1;
-                    hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8 * nsplit), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
-                                       cend, lb * 65, nsplit);
+            auto narrow_split = [&](int kk, int nbs) {
+                // one column block per matrix: the row tiles are dealt to several workgroups (a launch of one workgroup per
+                // matrix leaves most of the chip idle at the batch sizes of large n)
+                const int ntiles = (n - kk - nbs + 63) / 64;
+                return ntiles >= 32 ? 8 : ntiles >= 16 ? 4 : ntiles >= 8 ? 2 : 1;
+            };
+            if (n - k0 > LU_WIDE_ROWS) {
+                constexpr int NBS = 8;
+                const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
+                for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
+                    hipLaunchKernelGGL((lu_panelr_kernel<NBS, 8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
+                    if (k0 + lb + NBS < cend) {
+                        const int nsplit = narrow_split(k0 + lb, NBS);
+                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8 * nsplit), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                                           cend, lb * 65, nsplit);
+                    }
+                }
+            } else {
+                constexpr int NBS = 16;
+                const int threads = (((n - k0 + 3) / 4 + 63) / 64) * 64;
+                for (int lb = 0; lb < 64 && k0 + lb < n; lb += NBS) {
+                    hipLaunchKernelGGL((lu_panelr_kernel<NBS, 4, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0 + lb, lb);
+                    if (k0 + lb + NBS < cend) {
+                        const int nsplit = narrow_split(k0 + lb, NBS);
+                        hipLaunchKernelGGL((lu_trail_kernel<NBS, LU_BIG_MAX_N, 4>), dim3(nsys8 * nsplit), dim3(256), 0, c->stream, w, k0 + lb, nsys, 1,
+                                           cend, lb * 65, nsplit);
+                    }
                 }
             }
         } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
@@ -111,7 +127,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     {
         KTimer kt(c, IDAHIP_K_LU_FINALIZE, nsys);
         hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB,
-                           n > LU_MAX_N ? 8 : 0, c->lu_variant >= 4 ? WP_MAX_ROWS : 0);
+                           n > LU_MAX_N ? 8 : 0, c->lu_variant >= 4 ? WP_MAX_ROWS : 0);  // (16 where <= LU_WIDE_ROWS rows were live)
     }
     return 0;
 }

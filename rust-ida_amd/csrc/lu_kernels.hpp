@@ -24,6 +24,7 @@
 //   * a final pass scatters rows to their pivoted positions (the reference layout the solve kernels stream).
 // Blocking changes neither the per-element operation order nor any operand, only when each update is applied.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace idahip {
@@ -330,6 +331,17 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, in
     }
 }
 
+// f(integral_constant<K>) for K = 0 .. min(N, wd) - 1, stopping at the first false: a loop the compiler cannot decline to unroll
+template <int K, int N, class F>
+__device__ __forceinline__ bool static_steps(F& f, int wd) {
+    if constexpr (K < N) {
+        if (K >= wd) return true;
+        if (!f(std::integral_constant<int, K>{})) return false;
+        return static_steps<K + 1, N>(f, wd);
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ panel, R rows per thread
 // lu_panel2_kernel for any number R of live rows per lane (rows t + i T of the live list): with narrow panels (NB = 8) and
 // R = 8 a 512-thread workgroup factors a panel of up to 4096 rows (R * NB * 2 = 128 VGPRs of panel entries). Used for the
@@ -411,7 +423,8 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
     __syncthreads();
 
     bool failed = false;
-    auto step = [&](const int k) -> bool {  // k is a compile-time constant after unrolling
+    auto step = [&](auto kconst) -> bool {  // one instantiation per pivot step: k is a constant (static register indices)
+        constexpr int k = decltype(kconst)::value;
         const int kc = k0 + k;
         const int par = k & 1;
         // candidate key of a live row: the bit pattern of |a| with the always-clear sign bit set (0 = no candidate);
@@ -527,11 +540,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
 #endif
         return true;
     };
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (k >= wd) break;
-        if (!step(k)) { failed = true; break; }
-    }
+    failed = !static_steps<0, NB>(step, wd);
     STAMP(2);
     if (failed) return;
 
@@ -1306,7 +1315,8 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
         if (sp > 0) {
             // large n: the leading 64-column super-panels (more than LU_MAX_N live rows) are built from sp_lead-column panels
             // wp_rows > 0: super-panels with at most wp_rows live rows were factored 64 columns at a time (lu_wavepanel_kernel)
-            const int w_ = (wp_rows > 0 && n - (p & ~63) <= wp_rows) ? 64 : (sp_lead > 0 && n - (p & ~63) > LU_MAX_N) ? sp_lead : sp;
+            const int liv = n - (p & ~63);  // live rows when the super-panel of pivot position p was factored
+            const int w_ = (wp_rows > 0 && liv <= wp_rows) ? 64 : (sp_lead > 0 && liv > LU_MAX_N) ? (liv > LU_WIDE_ROWS ? sp_lead : 2 * sp_lead) : sp;
             const int spend = (p / w_ + 1) * w_;  // first column right of the panel that made row p a pivot row
             je = je < spend ? je : spend;
         }
