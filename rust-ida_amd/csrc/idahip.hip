@@ -998,8 +998,16 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     a.rounds_done = (long long*)c->tiny_rounds;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, batch);
-        if (c->kind == IDAHIP_ROBERTS) hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_ROBERTS>, dim3((batch + 63) / 64), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_LORENZ63>, dim3((batch + 63) / 64), dim3(64), 0, c->stream, a);
+        // LDS: the 64 controller records of a workgroup, and the systems' vectors too when the device grants that much
+        const size_t lds_state = 64 * sizeof(idactl::SysCore), lds_all = lds_state + 64 * sizeof(double) * tiny_lds_doubles(n);
+        const void* fn = c->kind == IDAHIP_ROBERTS ? (const void*)tiny_ida_kernel<IDAHIP_ROBERTS> : (const void*)tiny_ida_kernel<IDAHIP_LORENZ63>;
+        const int lds_vec = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) == hipSuccess ? 1 : 0;
+        if (!lds_vec) (void)hipGetLastError();
+        const size_t shm = lds_vec ? lds_all : lds_state;
+        if (c->kind == IDAHIP_ROBERTS)
+            hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_ROBERTS>, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
+        else
+            hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_LORENZ63>, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
         if ((rc = post_launch(c, "tiny_ida"))) return rc;
     }
     IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));

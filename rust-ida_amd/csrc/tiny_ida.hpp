@@ -46,7 +46,8 @@ struct TinyIdaArgs {
 struct TinyVec {
     const TinyIdaArgs& a;
     const int b, n;
-    const long vb;
+    const long vb;   // offset of the system's vectors in a.v's arrays (0 when they are this thread's block of LDS)
+    const long gvb;  // offset of the system in the global arrays (initial conditions)
 
     __device__ double& phi(int j, int i) const { return a.v.phi[j * a.v.phistride + vb + i]; }
 
@@ -167,7 +168,7 @@ struct TinyVec {
     }
     __device__ void restore_initial() const {  // Ida::new again: restore_initial_kernel
         for (int i = 0; i < n; ++i) {
-            const double y = a.ic_y[vb + i], yp = a.ic_yp[vb + i];
+            const double y = a.ic_y[gvb + i], yp = a.ic_yp[gvb + i];
             phi(0, i) = y;
             phi(1, i) = yp;
             a.v.yy[vb + i] = y;
@@ -183,7 +184,8 @@ struct TinyNewton {
     const TinyIdaArgs& a;
     idactl::SysCore& s;
     const int b, n;
-    const long vb;
+    const long vb;   // as in TinyVec
+    const long lub;  // offset of the system's matrix in a.lu
 
     // idaNlsResidual
     __device__ void nls_sys(bool reset_ee) const {
@@ -213,7 +215,7 @@ struct TinyNewton {
         for (int i = 0; i < n; ++i) y[i] = a.v.yy[vb + i];
         if (KIND == IDAHIP_ROBERTS) roberts_jac(s.cj, y, J);
         else lorenz_jac(a.params + (long)b * a.nparam, s.cj, y, J);
-        double* M = a.lu + (long)b * n * n;
+        double* M = a.lu + lub;
         for (int e = 0; e < n * n; ++e) M[e] = J[e];
         int lperm[TINY_N];
         return tiny_getrf(M, n, a.piv + vb, lperm);
@@ -222,7 +224,7 @@ struct TinyNewton {
     __device__ double newton_iter() const {
         double vv[TINY_N];
         for (int i = 0; i < n; ++i) vv[i] = -a.v.delta[vb + i];
-        tiny_getrs(a.lu + (long)b * n * n, n, a.piv + vb, vv);
+        tiny_getrs(a.lu + lub, n, a.piv + vb, vv);
         const double sc = s.cjratio != 1.0 ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:406-410
         double acc = 0.0;
         for (int i = 0; i < n; ++i) {
@@ -278,14 +280,52 @@ struct TinyNewton {
     }
 };
 
+// doubles of LDS one system's vectors take: phi[6], yy, yp, yypredict, yppredict, ewt, ee, delta, savres (14 n), the Jacobian /
+// its factors (n^2) and the pivots (n)
+__host__ __device__ constexpr int tiny_lds_doubles(int n) { return 14 * n + n * n + n; }
+
+// Everything a system owns sits in LDS for the length of the launch -- the controller record (736 B) and, when the launch was
+// given room for them (lds_vec), its vectors and its Jacobian: one lane walks dependent fp64 chains, and what it waits for is
+// the latency of its own state (scratch and global memory: ~500 cycles a touch; LDS: ~60). The vector code is the same either way: the
+// per-thread copy of the arguments points each field at this thread's block and the offsets vb / lub are zero. Config 2 (Lorenz63, 1024 systems): 26.0 -> 31.0 M iterations/s with the controller
+// record alone.
 template <int KIND>
-__global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs a) {
+__global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_vec) {
+    extern __shared__ __align__(16) unsigned char tiny_sm[];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.f.batch) return;
-    idactl::SysCore s = a.sys[b];
-    TinyVec v{a, b, a.v.n, (long)b * a.v.n};
+    if (b >= ga.f.batch) return;
+    idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(tiny_sm + threadIdx.x * sizeof(idactl::SysCore));
+    s = ga.sys[b];
+    TinyIdaArgs a = ga;
+    const int n = ga.v.n;
+    const long gvb = (long)b * n;
+    double* blk = reinterpret_cast<double*>(tiny_sm + 64 * sizeof(idactl::SysCore)) + (long)threadIdx.x * tiny_lds_doubles(n);
+    if (lds_vec) {
+        for (int j = 0; j < MXORDP1; ++j)
+            for (int i = 0; i < n; ++i) blk[j * n + i] = ga.v.phi[j * ga.v.phistride + gvb + i];
+        double* const src[8] = {ga.v.yy, ga.v.yp, ga.v.yypredict, ga.v.yppredict, ga.v.ewt, ga.v.ee, ga.v.delta, ga.savres};
+        for (int f = 0; f < 8; ++f)
+            for (int i = 0; i < n; ++i) blk[(6 + f) * n + i] = src[f][gvb + i];
+        for (int e = 0; e < n * n; ++e) blk[14 * n + e] = ga.lu[(long)b * n * n + e];
+        long long* pv = reinterpret_cast<long long*>(blk + 14 * n + n * n);
+        for (int i = 0; i < n; ++i) pv[i] = ga.piv[gvb + i];
+        a.v.phi = blk;  // every field is indexed from 0 (vb = 0 below)
+        a.v.phistride = n;
+        a.v.yy = blk + 6 * n;
+        a.v.yp = blk + 7 * n;
+        a.v.yypredict = blk + 8 * n;
+        a.v.yppredict = blk + 9 * n;
+        a.v.ewt = blk + 10 * n;
+        a.v.ee = blk + 11 * n;
+        a.v.delta = blk + 12 * n;
+        a.savres = blk + 13 * n;
+        a.lu = blk + 14 * n;
+        a.piv = pv;
+    }
+    const long vb = lds_vec ? 0 : gvb, lub = lds_vec ? 0 : (long)b * n * n;
+    TinyVec v{a, b, n, vb, gvb};
     const IdaFlow<TinyVec> F{a.f, s, v};
-    const TinyNewton<KIND> N{a, s, b, a.v.n, (long)b * a.v.n};
+    const TinyNewton<KIND> N{a, s, b, n, vb, lub};
     long long ground = a.round_base;  // global round counter (idaens_stream: every system takes part in every round)
     long long done = 0;
     bool stepping = F.enter(ground, b);
@@ -309,8 +349,18 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs a) {
             if (!stepping && s.status < 0) break;  // failed while streaming: the host reports it
         }
     }
-    a.sys[b] = s;
-    a.rounds_done[b] = done;
+    if (lds_vec) {
+        for (int j = 0; j < MXORDP1; ++j)
+            for (int i = 0; i < n; ++i) ga.v.phi[j * ga.v.phistride + gvb + i] = blk[j * n + i];
+        double* const dst[8] = {ga.v.yy, ga.v.yp, ga.v.yypredict, ga.v.yppredict, ga.v.ewt, ga.v.ee, ga.v.delta, ga.savres};
+        for (int f = 0; f < 8; ++f)
+            for (int i = 0; i < n; ++i) dst[f][gvb + i] = blk[(6 + f) * n + i];
+        for (int e = 0; e < n * n; ++e) ga.lu[(long)b * n * n + e] = blk[14 * n + e];
+        const long long* pv = reinterpret_cast<const long long*>(blk + 14 * n + n * n);
+        for (int i = 0; i < n; ++i) ga.piv[gvb + i] = pv[i];
+    }
+    ga.sys[b] = s;
+    ga.rounds_done[b] = done;
 }
 
 }  // namespace idahip
