@@ -972,8 +972,8 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     if (!c) return -1;
     if (!hSys || !call || !hRoundsDone || !hAcc || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
     if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
-    if (c->n > TINY_N || (c->kind != IDAHIP_ROBERTS && c->kind != IDAHIP_LORENZ63))
-        return fail(c, -2, "the device-resident stepper takes the Roberts and Lorenz63 problems (n <= %d)", TINY_N);
+    if (c->n != 3 || (c->kind != IDAHIP_ROBERTS && c->kind != IDAHIP_LORENZ63))
+        return fail(c, -2, "the device-resident stepper takes the Roberts and Lorenz63 problems (n = 3)");
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;

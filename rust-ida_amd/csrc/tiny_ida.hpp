@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(tiny_sm + threadIdx.x * sizeof(idactl::SysCore));
     s = ga.sys[b];
     TinyIdaArgs a = ga;
-    const int n = ga.v.n;
+    constexpr int n = 3;  // Roberts and Lorenz63 (idahip_create insists): a constant lets every vector loop unroll into registers
     const long gvb = (long)b * n;
     double* blk = reinterpret_cast<double*>(tiny_sm + 64 * sizeof(idactl::SysCore)) + (long)threadIdx.x * tiny_lds_doubles(n);
     if (lds_vec) {
