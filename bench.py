@@ -241,13 +241,18 @@ def cpu_baseline(prob_small, cores):
     the same workload: the first len(sample) systems, integrated over the whole horizon like the GPU run."""
     import oracle_lib as O
     n = prob_small["n"]
-    r = O.run_ensemble(prob_small["kind"], n, prob_small["yy0"], prob_small["yp0"], prob_small["rtol"], prob_small["atol"],
-                       prob_small["touts"], params=prob_small.get("params"), A=prob_small.get("A"), B=prob_small.get("B"),
-                       c=prob_small.get("c"), nthreads=cores)
-    iters = int(r["counters"]["nni"].sum())
-    return {"value": iters / r["seconds"], "unit": "Newton iters/s", "cores": cores, "kind": "port",
-            "sample": "%d systems of the same N=%d workload, full t=0..%g integration, %d Newton iterations in %.2f s, one std::thread per core"
-                      % (prob_small["yy0"].shape[0], n, float(prob_small["touts"][-1]), iters, r["seconds"])}
+    iters, seconds, reps = 0, 0.0, 0
+    while reps == 0 or (seconds < 5.0 and reps < 400):  # small systems: an integration of the sample is milliseconds; repeat it
+        r = O.run_ensemble(prob_small["kind"], n, prob_small["yy0"], prob_small["yp0"], prob_small["rtol"], prob_small["atol"],
+                           prob_small["touts"], params=prob_small.get("params"), A=prob_small.get("A"), B=prob_small.get("B"),
+                           c=prob_small.get("c"), nthreads=cores)
+        iters += int(r["counters"]["nni"].sum())
+        seconds += r["seconds"]
+        reps += 1
+    return {"value": iters / seconds, "unit": "Newton iters/s", "cores": cores, "kind": "port",
+            "sample": "%d systems of the same N=%d workload, full t=0..%g integration%s, %d Newton iterations in %.2f s, one std::thread per core"
+                      % (prob_small["yy0"].shape[0], n, float(prob_small["touts"][-1]), (" repeated %d times" % reps) if reps > 1 else "",
+                         iters, seconds)}
 
 
 def launch_ranks(n):
