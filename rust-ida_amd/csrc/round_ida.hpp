@@ -202,10 +202,22 @@ struct WgVec {
 };
 
 // ---- begin of a round: who steps, begin_attempt + prediction, which residual kernel serves the system
+// The workgroup (one wavefront) keeps ONE copy of its system's controller record, in LDS: every lane runs the scalar logic
+// on it in lock-step (same loads, same stores of the same values). A private copy per lane meant 64 reads and a spilled
+// 736-byte struct per system and kernel.
+static_assert(sizeof(idactl::SysCore) % 8 == 0 && WG_NT == 64, "word copies of the record; one wave per workgroup");
+__device__ __forceinline__ void wg_copy_words(void* dst, const void* src) {
+    for (int i = threadIdx.x; i < (int)(sizeof(idactl::SysCore) / 8); i += WG_NT)
+        static_cast<unsigned long long*>(dst)[i] = static_cast<const unsigned long long*>(src)[i];
+}
+
 __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
-    idactl::SysCore s = a.sys[b];
+    __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
+    wg_copy_words(s_raw, a.sys + b);
+    __syncthreads();
+    idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
     const IdaFlow<WgVec> F{a.f, s, v};
     const long long ground = a.round_base + a.round;
@@ -223,8 +235,8 @@ __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
         }
     }
     __syncthreads();
+    wg_copy_words(a.sys + b, s_raw);
     if (threadIdx.x == 0) {
-        a.sys[b] = s;
         a.stepping[b] = stepping ? 1 : 0;
         a.in_newton[b] = kind != 0;
         a.skipP[b] = kind != 1;
@@ -331,7 +343,10 @@ __global__ void round_newton_ctl_kernel(RoundArgs a, int phase) {
 __global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
-    idactl::SysCore s = a.sys[b];
+    __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
+    wg_copy_words(s_raw, a.sys + b);
+    __syncthreads();
+    idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
     const IdaFlow<WgVec> F{a.f, s, v};
     bool stepping = a.stepping[b] != 0;
@@ -339,8 +354,8 @@ __global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
     const long long ground = a.round_base + a.round + 1;
     if (a.f.recycle) stepping = F.after_round_stream(stepping, ground, b, threadIdx.x == 0);
     __syncthreads();
+    wg_copy_words(a.sys + b, s_raw);
     if (threadIdx.x == 0) {
-        a.sys[b] = s;
         a.stepping[b] = stepping ? 1 : 0;
         if (stepping) atomicAdd(&a.summary[0], 1);
         else if (s.status < 0 && a.in_newton[b]) atomicAdd(&a.summary[1], 1);
