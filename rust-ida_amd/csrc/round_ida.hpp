@@ -285,58 +285,63 @@ __global__ __launch_bounds__(1024) void round_lists_kernel(RoundArgs a) {
 // phase 0: after the residual (and setup) kernels; phase 1..4: after the m-th newton_iter_kernel of the round
 __global__ void round_newton_ctl_kernel(RoundArgs a, int phase) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.f.batch || !a.in_newton[b]) return;
-    idactl::SysCore s = a.sys[b];
-    const int n = a.v.n;
-    if (phase == 0) {
-        s.nre += 1;  // sys(y0)
-        bool go = true;
-        if (a.skipL[b] == 0) {
-            idactl::after_lsetup(s, a.lu_info[b]);
-            if (s.nls_ret == idactl::NLS_LSETUP_RECVR) {
-                s.nconvfails += 1;  // jcur is true: no retry (newton.rs:146-153 with Q3)
-                go = false;
+    const bool mine = b < a.f.batch && a.in_newton[b] && (phase == 0 || a.skipI[b] == 0);
+    // counters of the per-class statistics: one atomic per wavefront, not one per system
+    const unsigned long long m_iter = __ballot(mine && phase != 0);
+    if (m_iter != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&a.stats[IDAHIP_K_NEWTON_ITER], (unsigned long long)__popcll(m_iter));
+    bool again = false;
+    if (mine) {
+        idactl::SysCore& s = a.sys[b];  // in place: the few fields this step touches, not the 736-byte record both ways
+        const int n = a.v.n;
+        if (phase == 0) {
+            s.nre += 1;  // sys(y0)
+            bool go = true;
+            if (a.skipL[b] == 0) {
+                idactl::after_lsetup(s, a.lu_info[b]);
+                if (s.nls_ret == idactl::NLS_LSETUP_RECVR) {
+                    s.nconvfails += 1;  // jcur is true: no retry (newton.rs:146-153 with Q3)
+                    go = false;
+                }
             }
-        }
-        if (go) {
-            s.curiter = 0;
-            a.skipI[b] = 0;
-            a.scale[b] = s.cjratio != 1.0 ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:406-410
-        }
-    } else {
-        if (a.skipI[b] != 0) return;
-        a.skipS[b] = 1;
-        atomicAdd(&a.stats[IDAHIP_K_NEWTON_ITER], 1ull);
-        const double delnrm = sqrt(a.nrm_out[b] / (double)n);
-        s.niters += 1;
-        bool converged = false;
-        int ret = idactl::conv_test(s, delnrm, &converged);
-        if (ret == idactl::NLS_SUCCESS && converged) {
-            s.jcur = false;
-            s.nls_ret = idactl::NLS_SUCCESS;
-            a.skipI[b] = 1;
+            if (go) {
+                s.curiter = 0;
+                a.skipI[b] = 0;
+                a.scale[b] = s.cjratio != 1.0 ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:406-410
+            }
         } else {
-            if (ret == idactl::NLS_SUCCESS) {
-                s.curiter += 1;
-                if (s.curiter >= idactl::MAXNLSIT) ret = idactl::NLS_CONV_RECVR;
-            }
-            if (ret == idactl::NLS_SUCCESS) {
-                a.skipS[b] = 0;  // sys(y), then iterate again
-                s.nre += 1;
-                atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
-            } else {
-                s.nconvfails += 1;  // ConvergenceRecover
+            a.skipS[b] = 1;
+            const double delnrm = sqrt(a.nrm_out[b] / (double)n);
+            s.niters += 1;
+            bool converged = false;
+            int ret = idactl::conv_test(s, delnrm, &converged);
+            if (ret == idactl::NLS_SUCCESS && converged) {
+                s.jcur = false;
+                s.nls_ret = idactl::NLS_SUCCESS;
                 a.skipI[b] = 1;
-                if (!s.jcur) {
-                    s.call_lsetup = true;
-                    s.newton_retry = true;  // sys(y0) + setup + iterations again: in the next round
+            } else {
+                if (ret == idactl::NLS_SUCCESS) {
+                    s.curiter += 1;
+                    if (s.curiter >= idactl::MAXNLSIT) ret = idactl::NLS_CONV_RECVR;
+                }
+                if (ret == idactl::NLS_SUCCESS) {
+                    a.skipS[b] = 0;  // sys(y), then iterate again
+                    s.nre += 1;
+                    again = true;
                 } else {
-                    s.nls_ret = idactl::NLS_CONV_RECVR;
+                    s.nconvfails += 1;  // ConvergenceRecover
+                    a.skipI[b] = 1;
+                    if (!s.jcur) {
+                        s.call_lsetup = true;
+                        s.newton_retry = true;  // sys(y0) + setup + iterations again: in the next round
+                    } else {
+                        s.nls_ret = idactl::NLS_CONV_RECVR;
+                    }
                 }
             }
         }
     }
-    a.sys[b] = s;
+    const unsigned long long m_sys = __ballot(again);
+    if (m_sys != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&a.stats[IDAHIP_K_SYS], (unsigned long long)__popcll(m_sys));
 }
 
 // ---- end of a round: the rest of the attempt, the schedule, Ida::new again when streaming, the round's summary
