@@ -393,6 +393,37 @@ impl Counter {
 pub struct HipEnsemble {
     raw: *mut sys::idaens,
     ctx: Ctx,
+    root: Option<Box<RootBox>>, // the user's `Root` function, kept alive while the library holds a pointer to it
+}
+
+/// `Root::root` (src/traits.rs:72-90) for a batch: `gout = g(t, yy, yp)` of system `sys`. Evaluated on the host with y(t), y'(t)
+/// interpolated on the device (`idaens_set_root_fn`); a panic fails that system with `IDAENS_RTFUNC_FAIL`.
+pub trait HostRoot {
+    fn num_roots(&self) -> usize;
+    fn root(&self, sys: usize, t: f64, yy: &[f64], yp: &[f64], gout: &mut [f64]);
+}
+
+struct RootBox {
+    n: usize,
+    root: Box<dyn HostRoot>,
+}
+
+unsafe extern "C" fn root_trampoline(user: *mut c_void, s: i32, t: c_double, yy: *const c_double, yp: *const c_double, nroots: i32, gout: *mut c_double) -> c_int {
+    let cb = &*(user as *const RootBox);
+    let out = catch_unwind(AssertUnwindSafe(|| {
+        cb.root.root(
+            s as usize,
+            t,
+            std::slice::from_raw_parts(yy, cb.n),
+            std::slice::from_raw_parts(yp, cb.n),
+            std::slice::from_raw_parts_mut(gout, nroots as usize),
+        )
+    }));
+    if out.is_ok() {
+        0
+    } else {
+        1
+    }
 }
 
 unsafe impl Send for HipEnsemble {}
@@ -407,7 +438,7 @@ impl HipEnsemble {
         if rc != 0 || raw.is_null() {
             return Err(Error::Library { code: rc, message: ctx.last_error() });
         }
-        Ok(HipEnsemble { raw, ctx })
+        Ok(HipEnsemble { raw, ctx, root: None })
     }
 
     fn last_error(&self) -> String {
@@ -440,6 +471,19 @@ impl HipEnsemble {
         if rc != 0 {
             return Err(Error::Library { code: rc, message: self.last_error() });
         }
+        Ok(())
+    }
+
+    /// Any `Root` implementor (src/traits.rs:72-90) as the root functions of every system, before the first `solve`.
+    pub fn set_root_fn(&mut self, root: Box<dyn HostRoot>) -> Result<(), Error> {
+        let nroots = root.num_roots();
+        let mut boxed = Box::new(RootBox { n: self.ctx.n, root });
+        let user = &mut *boxed as *mut RootBox as *mut c_void;
+        let rc = unsafe { sys::idaens_set_root_fn(self.raw, nroots as c_int, Some(root_trampoline), user) };
+        if rc != 0 {
+            return Err(Error::Library { code: rc, message: self.last_error() });
+        }
+        self.root = Some(boxed);
         Ok(())
     }
 

@@ -37,6 +37,8 @@ enum {
     IDAENS_CONV_FAIL = -4,
     IDAENS_LSETUP_FAIL = -6,
     IDAENS_CLOSE_ROOTS = -10, /* IdaError::CloseRoots (impl_r_check.rs:199) */
+    IDAENS_RTFUNC_FAIL = -12, /* a host root function returned non-zero (C IDA's IDA_RTFUNC_FAIL; the reference has the check
+                                 commented out, impl_r_check.rs:83) */
     IDAENS_ILL_INPUT = -22,
     IDAENS_BAD_K = -25,
     IDAENS_BAD_T = -26
@@ -73,6 +75,12 @@ int idaens_set_device_controller(idaens* e, int on);
  * functions are this parametrised family. */
 int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds);
 int idaens_get_roots(const idaens* e, int32_t* out /* [batch][nroots] */);
+/* Root::root (src/traits.rs:72-90) for any user function: gout[0..nroots) = g(t, yy, yp) of system `sys`, evaluated on the
+ * host with y(t), y'(t) interpolated on the device and copied back (yy, yp: n doubles, valid during the call). Return 0, or
+ * non-zero to fail that system with IDAENS_RTFUNC_FAIL. Replaces idaens_set_roots' family; same calling rules. The bracketing
+ * (impl_r_check.rs) is per-system scalar work on the host either way: roots are rare events of single systems. */
+typedef int (*idaens_root_fn)(void* user, int32_t sys, double t, const double* yy, const double* yp, int32_t nroots, double* gout);
+int idaens_set_root_fn(idaens* e, int nroots, idaens_root_fn fn, void* user);
 
 /* Ida::solve(tout, &mut tret, itask) for every system (src/impl_solve.rs:69-376). hTret/hStatus: [batch].
  * max_rounds > 0 bounds the number of lock-step attempt rounds (systems still stepping report IDAENS_UNFINISHED and

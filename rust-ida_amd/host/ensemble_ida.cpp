@@ -79,6 +79,8 @@ struct idaens {
     int nrtfn = 0;
     std::vector<int32_t> rt_comp;
     std::vector<double> rt_thr;
+    idaens_root_fn rt_fn = nullptr;  // or any host function (idaens_set_root_fn)
+    void* rt_user = nullptr;
     std::vector<double> hy, hyp;  // host copies of one system's y, y' for the root functions
     // scratch for list calls
     std::vector<int32_t> idx, ia, ib;
@@ -185,8 +187,10 @@ int flush_solutions(idaens* e, SolList& sl) {
 // ---------------------------------------------------------------- root finding (src/impl_r_check.rs:32-576)
 // Roots are rare events of single systems: the bracketing runs system by system on the host, with the device
 // interpolating y(t), y'(t) (idahip_get_solution) and the two vectors coming back for the root functions.
-void root_fn(const idaens* e, const double* y, double* g) {
+int root_fn(const idaens* e, int b, double t, const double* y, const double* yp, double* g) {
+    if (e->rt_fn) return e->rt_fn(e->rt_user, b, t, y, yp, e->nrtfn, g) == 0 ? 0 : IDAENS_RTFUNC_FAIL;
     for (int i = 0; i < e->nrtfn; ++i) g[i] = y[e->rt_comp[i]] - e->rt_thr[i];
+    return 0;
 }
 
 // get_solution(t) of system b on the device (yy, yp of that system become y(t), y'(t), lib.rs:1274), copy to e->hy, e->hyp
@@ -212,7 +216,7 @@ int r_check1(idaens* e, int b) {
     s.ttol = (std::fabs(s.tn) + std::fabs(s.hh)) * eps * 100.0;
     ENS_CALL(e, idahip_download(e->ctx, IDAHIP_F_PHI0, b, 1, e->hy.data()));
     ENS_CALL(e, idahip_download(e->ctx, (idahip_field)(IDAHIP_F_PHI0 + 1), b, 1, e->hyp.data()));
-    root_fn(e, e->hy.data(), s.glo.data());
+    if (int rf = root_fn(e, b, s.tlo, e->hy.data(), e->hyp.data(), s.glo.data())) return rf;
     s.nge = 1;
     bool zroot = false;
     for (int i = 0; i < nr; ++i)
@@ -225,7 +229,7 @@ int r_check1(idaens* e, int b) {
         const double smallh = hratio * s.hh;
         for (int i = 0; i < n; ++i) e->hy[i] = e->hy[i] + smallh * e->hyp[i];  // yy = phi[0] + smallh * phi[1]
         ENS_CALL(e, idahip_upload(e->ctx, IDAHIP_F_YY, b, 1, e->hy.data()));
-        root_fn(e, e->hy.data(), s.ghi.data());
+        if (int rf = root_fn(e, b, s.tlo + smallh, e->hy.data(), e->hyp.data(), s.ghi.data())) return rf;
         s.nge += 1;
         for (int i = 0; i < nr; ++i)
             if (!s.gactive[i] && std::fabs(s.ghi[i]) != 0.0) {
@@ -244,7 +248,7 @@ int r_check2(idaens* e, int b) {
     if (!s.irfnd) return IDAENS_UNFINISHED;
     int rc = interp_now(e, b, s.tlo);
     if (rc) return rc;
-    root_fn(e, e->hy.data(), s.glo.data());
+    if (int rf = root_fn(e, b, s.tlo, e->hy.data(), e->hyp.data(), s.glo.data())) return rf;
     s.nge += 1;
     std::fill(s.iroots.begin(), s.iroots.end(), 0.0);
     bool zroot = false;
@@ -267,7 +271,7 @@ int r_check2(idaens* e, int b) {
             rc = interp_now(e, b, tplus);
             if (rc) return rc;
         }
-        root_fn(e, e->hy.data(), s.ghi.data());
+        if (int rf = root_fn(e, b, tplus, e->hy.data(), e->hyp.data(), s.ghi.data())) return rf;
         s.nge += 1;
         bool zroot2 = false;
         for (int i = 0; i < nr; ++i) {
@@ -348,7 +352,7 @@ int root_find(idaens* e, int b) {
         }
         const int rc = interp_now(e, b, tmid);
         if (rc) return rc;
-        root_fn(e, e->hy.data(), s.grout.data());
+        if (int rf = root_fn(e, b, tmid, e->hy.data(), e->hyp.data(), s.grout.data())) return rf;
         s.nge += 1;
         sideprev = side;
         scan_roots(e, s, s.grout, false, &zroot, &sgnchg, &imax);
@@ -387,7 +391,7 @@ int r_check3(idaens* e, int b) {
     else s.thi = ((s.toutc - s.tn) * s.hh >= 0.0) ? s.tn : s.toutc;
     int rc = interp_now(e, b, s.thi);
     if (rc) return rc;
-    root_fn(e, e->hy.data(), s.ghi.data());
+    if (int rf = root_fn(e, b, s.thi, e->hy.data(), e->hyp.data(), s.ghi.data())) return rf;
     s.nge += 1;
     s.ttol = (std::fabs(s.tn) + std::fabs(s.hh)) * eps * 100.0;
     const int ier = root_find(e, b);
@@ -981,9 +985,18 @@ int solve_core(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long ma
                     fac.push_back(s.hh);
                 }
                 if (e->nrtfn > 0)
-                    for (int b : ok) {  // impl_solve.rs:157-159
-                        const int rc1 = r_check1(e, b);
+                    for (size_t q = 0; q < ok.size();) {  // impl_solve.rs:157-159
+                        const int rc1 = r_check1(e, ok[q]);
+                        if (rc1 == IDAENS_RTFUNC_FAIL) {  // the user's root function failed for this system: it never starts
+                            S[ok[q]].status = rc1;
+                            S[ok[q]].tret = S[ok[q]].tn;
+                            S[ok[q]].dead = true;
+                            ok.erase(ok.begin() + q);
+                            fac.erase(fac.begin() + q);
+                            continue;
+                        }
                         if (rc1) return rc1;
+                        ++q;
                     }
                 if (!ok.empty()) ENS_CALL(e, idahip_scale_phi1(e->ctx, fac.data(), ok.data(), (int)ok.size()));  // phi[1] = hh*y'
             }
@@ -1165,15 +1178,11 @@ int idaens_solve_schedule(idaens* e, const double* touts, int ntout, double* hTr
     return solve_core(e, C, hTret, hStatus, max_rounds);
 }
 
-int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds) {
-    if (!e || nroots < 0 || (nroots > 0 && (!comps || !thresholds))) return -1;
-    for (int i = 0; i < nroots; ++i)
-        if (comps[i] < 0 || comps[i] >= e->n) return efail(e, -2, "root function %d: component %d outside 0..%d", i, comps[i], e->n - 1);
+namespace {
+int install_roots(idaens* e, int nroots) {
     for (const Sys& s : e->sys)
         if (s.nst > 0 || s.setup_done) return efail(e, -2, "root functions must be set before the first solve call");
     e->nrtfn = nroots;
-    e->rt_comp.assign(comps, comps + nroots);
-    e->rt_thr.assign(thresholds, thresholds + nroots);
     e->hy.assign(e->n, 0.0);
     e->hyp.assign(e->n, 0.0);
     for (Sys& s : e->sys) {
@@ -1183,6 +1192,30 @@ int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* 
         s.iroots.assign(nroots, 0.0);
         s.gactive.assign(nroots, 0);  // sic: false (lib.rs:373); r_check1/3 switch them on
     }
+    return 0;
+}
+}  // namespace
+
+int idaens_set_roots(idaens* e, int nroots, const int32_t* comps, const double* thresholds) {
+    if (!e || nroots < 0 || (nroots > 0 && (!comps || !thresholds))) return -1;
+    for (int i = 0; i < nroots; ++i)
+        if (comps[i] < 0 || comps[i] >= e->n) return efail(e, -2, "root function %d: component %d outside 0..%d", i, comps[i], e->n - 1);
+    const int rc = install_roots(e, nroots);
+    if (rc) return rc;
+    e->rt_fn = nullptr;
+    e->rt_comp.assign(comps, comps + nroots);
+    e->rt_thr.assign(thresholds, thresholds + nroots);
+    return 0;
+}
+
+int idaens_set_root_fn(idaens* e, int nroots, idaens_root_fn fn, void* user) {
+    if (!e || nroots < 0 || (nroots > 0 && !fn)) return -1;
+    const int rc = install_roots(e, nroots);
+    if (rc) return rc;
+    e->rt_fn = nroots > 0 ? fn : nullptr;
+    e->rt_user = user;
+    e->rt_comp.clear();
+    e->rt_thr.clear();
     return 0;
 }
 

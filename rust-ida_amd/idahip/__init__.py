@@ -23,6 +23,7 @@ KIND = {"roberts": ROBERTS, "lorenz63": LORENZ63, "linear_dense": LINEAR_DENSE, 
 RES_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 JAC_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                      C.POINTER(C.c_double), C.c_void_p)
+ROOT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double))
 F_YY, F_YP, F_YYPREDICT, F_YPPREDICT, F_EWT, F_EE, F_DELTA, F_SAVRES, F_PHI0 = range(9)
 K_NEWTON_ITER, K_SYS, K_JAC, K_LU, K_VECTOR, K_SOLVE, K_SYS_JAC = range(7)
 K_NAMES = ["newton_iter", "sys", "jac", "lu", "vector", "solve", "sys_jac", "lu_panel", "lu_trail", "lu_finalize"]
@@ -39,7 +40,7 @@ HIP_SYMBOLS = [
     "idahip_restore_initial",
 ]
 ENS_SYMBOLS = [
-    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots",
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots", "idaens_set_root_fn",
     "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
@@ -121,6 +122,7 @@ def load():
     E.idaens_set_fused_newton.argtypes = [vp, ci]
     E.idaens_set_device_controller.argtypes = [vp, ci]
     E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
+    E.idaens_set_root_fn.argtypes = [vp, ci, ROOT_FN, vp]
     E.idaens_get_roots.argtypes = [vp, i32p]
     E.idaens_solve.argtypes = [vp, cd, ci, dp, i32p, C.c_long]
     E.idaens_solve_schedule.argtypes = [vp, dp, ci, dp, i32p, i32p, dp, dp, C.c_long]
@@ -434,6 +436,26 @@ class Ensemble:
         if self.E.idaens_set_roots(self.h, comps.size, _p(comps, i32p), _p(thr)) != 0:
             raise IdaHipError("set_roots: %s" % (self.E.idaens_last_error(self.h) or b"").decode())
         self.nroots = comps.size
+
+    def set_root_fn(self, nroots, fn):
+        """Root::root for any function: fn(sys, t, yy, yp) -> nroots values g_i (yy, yp: numpy views valid during the call).
+        An exception inside fn fails that system with IDAENS_RTFUNC_FAIL (-12) and is kept on the Ctx (`last_callback_error`)."""
+        ens = self
+
+        def thunk(user, sys, t, yy, yp, nr, gout):
+            try:
+                n = ens.ctx.n
+                g = fn(int(sys), float(t), np.ctypeslib.as_array(yy, (n,)), np.ctypeslib.as_array(yp, (n,)))
+                np.copyto(np.ctypeslib.as_array(gout, (nr,)), np.asarray(g, dtype=np.float64).reshape(nr))
+                return 0
+            except Exception as e:  # cannot cross the C boundary
+                ens.ctx._cb_error = e
+                return 1
+
+        self._root_thunk = ROOT_FN(thunk)  # keep it alive as long as the ensemble
+        if self.E.idaens_set_root_fn(self.h, int(nroots), self._root_thunk, None) != 0:
+            raise IdaHipError("set_root_fn: %s" % (self.E.idaens_last_error(self.h) or b"").decode())
+        self.nroots = int(nroots)
 
     def roots_found(self):
         out = np.zeros((self.ctx.batch, getattr(self, "nroots", 0)), dtype=np.int32)

@@ -305,6 +305,69 @@ def test_roberts_example_with_root_finding():
     assert (c["nni"] == 537).all() and (c["netf"] == 15).all()
 
 
+def test_user_root_function_through_the_host_callback():
+    """idaens_set_root_fn: the Root trait for any user function (src/traits.rs:72-90), evaluated on the host with y(t), y'(t)
+    interpolated on the device. (1) The Roberts example's two functions written as a callback reproduce the built-in family
+    return for return (status, t_ret, y, rootsfound, 404 evaluations). (2) A function of t alone, g = t - 0.5 on Lorenz63,
+    stops every system at t = 0.5 to within the bracketing tolerance. (3) A callback that raises fails only its own system
+    with IDAENS_RTFUNC_FAIL and the exception is kept."""
+    import idahip
+    from idahip import problems
+    R = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "roberts_example.json")))
+    p = problems.roberts()
+    B = 3
+    p["yy0"] = np.tile(p["yy0"], (B, 1))
+    p["yp0"] = np.tile(p["yp0"], (B, 1))
+    fam = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    fam.set_roots([0, 2], [0.0001, 0.01])
+    cb = idahip.Ensemble(problems.make_ctx(p), p["yy0"], p["yp0"])
+    calls = []
+
+    def g(sys, t, yy, yp):
+        calls.append(sys)
+        return [yy[0] - 0.0001, yy[2] - 0.01]
+
+    cb.set_root_fn(2, g)
+    tout, iout, nroot_returns = R["tout0"], 0, 0
+    while iout < R["nout"]:
+        st_f, tret_f = fam.solve(tout)
+        st, tret = cb.solve(tout)
+        assert np.array_equal(st, st_f) and np.array_equal(tret, tret_f)
+        assert np.array_equal(cb.yy(), fam.yy()) and np.array_equal(cb.yp(), fam.yp())
+        if st_f[0] == 2:
+            nroot_returns += 1
+            assert np.array_equal(cb.roots_found(), fam.roots_found())
+        else:
+            iout += 1
+            tout *= R["tout_factor"]
+    assert nroot_returns == 2 and (cb.counter("nge") == 404).all() and len(calls) == 404 * B
+    fam.close()
+    cb.close()
+
+    q = problems.lorenz63(batch=6)
+    ens = idahip.Ensemble(problems.make_ctx(q), q["yy0"], q["yp0"])
+    ens.set_root_fn(1, lambda sys, t, yy, yp: [t - 0.5])
+    st, tret = ens.solve(1.0)
+    assert (st == 2).all() and np.all(np.abs(tret - 0.5) < 1e-9)
+    assert (ens.roots_found() == -1).all()  # the reference reports glo.signum() (impl_r_check.rs:404): -1 for an increasing g
+    st, tret = ens.solve(1.0)  # past the root: the call now reaches tout
+    assert (st == 0).all() and np.array_equal(tret, np.full(6, 1.0))
+    ens.close()
+
+    ens = idahip.Ensemble(problems.make_ctx(q), q["yy0"], q["yp0"])
+
+    def bad(sys, t, yy, yp):
+        if sys == 4:
+            raise ValueError("no g for system 4")
+        return [yy[0] - 1.0e9]
+
+    ens.set_root_fn(1, bad)
+    st, tret = ens.solve(0.2)
+    assert st[4] == -12 and (np.delete(st, 4) == 0).all()
+    assert isinstance(ens.ctx._cb_error, ValueError)
+    ens.close()
+
+
 @pytest.mark.parametrize("kind", ["linear_dense", "lorenz63", "heat1d"])
 def test_output_schedule_equals_sequential_solve_calls(kind):
     """idaens_solve_schedule: every system runs solve(t1), solve(t2), ... without waiting for the others. The output at
