@@ -61,7 +61,7 @@ int idaens_set_fused_newton(idaens* e, int on);
  * (IDA_NORMAL, no root functions, no trace):
  *   - small systems (n <= 8: Roberts, Lorenz63): a solve / solve_schedule / stream call is ONE launch in which every system
  *     runs its own time loop (idahip_tiny_solve);
- *   - linear dense problems with 8 < n <= 512: lock-step rounds as below, but enqueued without a host round trip inside a
+ *   - linear dense problems with 8 < n <= 1024: lock-step rounds as below, but enqueued without a host round trip inside a
  *     round -- one synchronisation per round, none in idaens_stream (idahip_round_solve). A Newton solve that has to start
  *     over with a fresh Jacobian does so in the next round, so a system may need one round more than with the host stepper;
  *     its steps, orders, counters and results are the same.

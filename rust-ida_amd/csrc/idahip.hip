@@ -1054,8 +1054,8 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     if (!c) return -1;
     if (!hSys || !call || !hRoundsDone || !hAcc || !rounds_run || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
     if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
-    if (c->n <= TINY_N || c->n > WP_MAX_ROWS || c->kind != IDAHIP_LINEAR_DENSE || c->lu_variant < 4)
-        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4)", TINY_N, WP_MAX_ROWS);
+    if (c->n <= TINY_N || c->n > LU_MAX_N || c->kind != IDAHIP_LINEAR_DENSE || c->lu_variant < 4)
+        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4)", TINY_N, LU_MAX_N);
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;

@@ -10,7 +10,7 @@ namespace idahip {
 // (reference layout: rows at their pivoted positions). 64-column super-panels; per super-panel the panel factorisation
 // (by live rows: > 1024 lu_panelr, > 512 or variant 3 lu_panel2 + narrow update, else lu_wavepanel) and one launch of the
 // rank-64 trailing kernel; a final row scatter.
-// d_cnt (optional): the list's length lives on the device and nsys is only its upper bound (n <= WP_MAX_ROWS, variant 4 / 5).
+// d_cnt (optional): the list's length lives on the device and nsys is only its upper bound (n <= LU_MAX_N, variant 4).
 inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* out, long ostride, long long* piv, long pstride,
                              int* perm, const int* d_idx, int nsys, const int* d_cnt = nullptr) {
     const int n = c->n;
@@ -22,7 +22,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         return 0;
     }
     if (n > LU_BIG_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_BIG_MAX_N, n);
-    if (d_cnt && (n > WP_MAX_ROWS || c->lu_variant < 4)) return fail(c, -3, "a device-side list length needs the wave-per-matrix pipeline (n <= %d)", WP_MAX_ROWS);
+    if (d_cnt && (n > LU_MAX_N || c->lu_variant < 4)) return fail(c, -3, "a device-side list length needs the wave-per-matrix pipeline (n <= %d)", LU_MAX_N);
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.cnt = d_cnt; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;

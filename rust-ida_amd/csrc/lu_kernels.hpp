@@ -106,6 +106,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panel2_kernel(LuWs w, int k0, in
     constexpr int NW = MAXT / 64;
     constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
     static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
+    if (w.cnt && (int)blockIdx.x >= ldc(w.cnt)) return;  // (list length on the device: surplus workgroups leave)
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
     // Every workgroup of a split repeats the (small) pivot-row gather and U12 solve; split 0 writes U12 to the factors.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int split = slot % nsplit, cbi = (slot / nsplit) % ncb, mi = (slot / (nsplit * ncb)) * 8 + xcd;
-    if (mi >= nsys) return;
+    if (mi >= (w.cnt ? ldc(w.cnt) : nsys)) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
     const int n = w.n;

@@ -51,8 +51,8 @@ struct RoundArgs {
     int* summary;           // [2]: systems stepping after this round (zeroed before every round), systems that failed (this call)
 };
 
-// vector backend of IdaFlow: a workgroup of WG_NT threads (one wavefront: every thread carries its own copy of the controller
-// state, so fewer threads mean less redundant scalar work and private-memory traffic) owns system b; sums are accumulated left to right by one lane
+// vector backend of IdaFlow: a workgroup of WG_NT threads (one wavefront: every lane runs the scalar logic, in lock-step, on the
+// workgroup's one copy of the controller record in LDS) owns system b; sums are accumulated left to right by one lane
 // (seq_sum_lds) and broadcast through LDS, exactly as the batched kernels of vector_kernels.hpp do
 constexpr int WG_NT = 64;
 

@@ -125,9 +125,10 @@ def test_failures_are_reported_like_the_host_stepper():
     assert (sd == -1).any() or (sd == 0).all()
 
 
-@pytest.mark.parametrize("n,batch", [(24, 8), (64, 24), (200, 6)])
+@pytest.mark.parametrize("n,batch", [(24, 8), (64, 24), (200, 6), (704, 5), (1024, 3)])
 def test_device_lock_step_rounds_equal_host_stepper_and_oracle(n, batch):
-    """Linear dense problems, 8 < n <= 512: the rounds are enqueued from the host but decided on the device
+    """Linear dense problems, 8 < n <= 1024 (above 512 rows the leading super-panels of the LU take the workgroup-per-matrix
+    panel kernels, with the list's length on the device like everywhere else): the rounds are enqueued from the host but decided on the device
     (idahip_round_solve). Per system the same steps as the host stepper and the oracle; the number of rounds may differ (a
     Newton solve that starts over with a fresh Jacobian does so in the next round)."""
     from idahip import problems
