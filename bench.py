@@ -497,6 +497,23 @@ def main():
                        "note": "first starts spread over one median integration length (rounds), measured on the device on the "
                                "first %d systems before the stream starts; then the untimed spin-up, W warm-up and K timed rounds" % Runner.CALIBRATION_SYSTEMS},
         }
+        if args.workload == "linear_dense":
+            # north_star: the rate as a fraction of the HBM roofline. BASELINE.md section 3: one Newton iteration moves 24 N^2 + 80 N
+            # bytes (solve + residual), a linear-solver setup (40 N^2 + 8 N bytes: Jacobian + factor) is shared by the r iterations
+            # measured per setup in this run
+            N = args.n
+            it_bytes, ls_bytes = 24 * N * N + 80 * N, 40 * N * N + 8 * N
+            n_it = tim["newton_iter"]["systems"]
+            n_ls = tim["lu"]["systems"]
+            r = n_it / n_ls if n_ls else None
+            per_gpu = 8.0e12 / it_bytes
+            out["hbm_roofline"] = {
+                "iters_per_s_per_gpu": round(per_gpu), "frac": out["value"] / (world * per_gpu),
+                "newton_iters_per_lsetup": None if r is None else round(r, 2),
+                "iters_per_s_per_gpu_with_lsetup": None if r is None else round(8.0e12 / (it_bytes + ls_bytes / r)),
+                "frac_with_lsetup": None if r is None else out["value"] / (world * 8.0e12 / (it_bytes + ls_bytes / r)),
+                "note": "8 TB/s over the algorithmic bytes of BASELINE.md section 3; the factorisation itself is bound by the fp64 vector "
+                        "pipe at this N, not by HBM (`roofline`, `lu_plus_solve`)"}
         if extras:
             out.update(extras)
         if TIME_ALL:
