@@ -132,7 +132,9 @@ def lu_plus_solve(tim, n, arithmetic, dense=True):
     else:
         out["note"] = ("banded Jacobian in dense storage: the reference's a_kj == 0 rule (dense.rs:148) skips the updates of zero "
                        "pivot-row entries and so does the device (whole pivot rows and column blocks at a time), so a dense flop "
-                       "count does not describe this factorisation; the byte figure (matrix read + written once) does")
+                       "count does not describe this factorisation; the byte figure (matrix read + written once) describes the "
+                       "factorisation, while the triangular solves leave the factors' all-zero 64 x 64 blocks out (exactly) and move far "
+                       "less than 8 N^2 bytes")
     return out
 
 
@@ -417,8 +419,14 @@ def main():
             ent = {"ms": round(v["ms"], 3), "calls": v["launches"], "systems": v["systems"],
                    "share_of_device_time": round(v["ms"] / total_ms, 4) if total_ms > 0 else None}
             if ab.get(k) and v["ms"] > 0:
-                ent["GB/s"] = round(ab[k] * v["systems"] / (v["ms"] * 1e-3) / 1e9, 1)
-                ent["frac_of_hbm_peak"] = round(ent["GB/s"] / HBM_PEAK_GBS, 4)
+                gbs = round(ab[k] * v["systems"] / (v["ms"] * 1e-3) / 1e9, 1)
+                if args.workload == "heat1d" and k == "newton_iter":
+                    # the factors of the banded Jacobian are zero almost everywhere and the solves leave all-zero 64 x 64 blocks out
+                    # (exactly: solve_kernels.hpp): the dense byte count is not what moves, so no fraction of the peak is claimed
+                    ent["GB/s_dense_equivalent"] = gbs
+                else:
+                    ent["GB/s"] = gbs
+                    ent["frac_of_hbm_peak"] = round(gbs / HBM_PEAK_GBS, 4)
             classes[k] = ent
         lu_kernels = {}
         for k in ("lu_panel", "lu_trail", "lu_finalize"):

@@ -20,6 +20,7 @@ constexpr int TINY_N = 8;       // n <= TINY_N: one thread per system (whole New
 constexpr int LU_NB = 32;       // panel width of the blocked LU
 constexpr int LU_MAX_N = 1024;  // blocked LU, fast pipelines: at most two panel rows per lane of a 512-thread workgroup
 constexpr int LU_WIDE_ROWS = 2048;  // n > 1024: at most this many live rows -> 16-column panels with four rows per lane (above: 8 columns, eight rows)
+constexpr int LU_ZMAP_MIN_N = 2048;  // from this size on the factorisation leaves a map of the factors' zero blocks for the triangular solves
 constexpr int LU_BIG_MAX_N = 4096;  // blocked LU with eight panel rows per lane for the leading super-panels
 constexpr int NSLOT = 8;
 
@@ -59,6 +60,7 @@ struct idahip_ctx {
     int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr, *lu_nzb = nullptr, *lu_bz = nullptr;
+    uint8_t* lu_zmap = nullptr;  // [batch][64][64], n >= 2048: [K][I] = 1 when the 64 x 64 block (rows I, columns K) of the factors in `lu` may hold a non-zero
     double* lu_l11 = nullptr;
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)

@@ -95,6 +95,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     rc |= dalloc(c, &c->lu_redo, (size_t)batch);
     rc |= dalloc(c, &c->lu_nzb, (size_t)batch);
     if (n > LU_MAX_N) rc |= dalloc(c, &c->lu_bz, (size_t)batch * 64);
+    if (n >= LU_ZMAP_MIN_N) rc |= dalloc(c, &c->lu_zmap, (size_t)batch * 4096);
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
@@ -136,7 +137,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (!c) return 0;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
                     c->tiny_acc, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
@@ -591,13 +592,13 @@ static int launch_newton_iter(idahip_ctx* c, const int* d_idx, const double* d_s
                            (const long long*)c->piv, c->delta, c->ee, (const double*)c->ewt, n, d_idx, nsys, d_scale, d_out, d_skip);
     } else if (n % 2 == 0 && n >= 2048) {
         hipLaunchKernelGGL((newton_iter_kernel<2, 1024>), dim3(nsys), dim3(1024), sizeof(double) * (n + (n > 4096 ? n : 4096)), c->stream, (const double*)c->lu,
-                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip, (const unsigned char*)c->lu_zmap);
     } else if (n % 2 == 0) {
         hipLaunchKernelGGL(newton_iter_kernel<2>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip, (const unsigned char*)nullptr);
     } else {
         hipLaunchKernelGGL(newton_iter_kernel<1>, dim3(nsys), dim3(256), 2 * sizeof(double) * n, c->stream, (const double*)c->lu,
-                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip);
+                           (const int*)c->perm, c->delta, c->ee, (const double*)c->ewt, n, d_idx, d_scale, d_out, d_skip, (const unsigned char*)nullptr);
     }
     return post_launch(c, "newton_iter");
 }

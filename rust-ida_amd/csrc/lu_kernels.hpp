@@ -47,6 +47,7 @@ struct LuWs {
     int* info;         // [batch]   0 | 1-based zero-pivot column
     int* nzb;          // [batch]   lu_trail64w_kernel, n > 1024: column blocks of the first super-panel's update that had work
     int* bz;           // [batch][64] n > 1024: per column block of the current super-panel's update, 1 = its pivot rows have a non-zero entry
+    unsigned char* zmap;  // null, or [batch][64][64] (n >= 2048): zmap[K][I] = 1 when block (rows I, columns K) of the factors may be non-zero
     int* redo;         // [batch]   lu_wavepanel_kernel: 0 | 1 + first 8-column block of the super-panel left to its SLOW launch
     double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
     int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
@@ -67,6 +68,8 @@ __global__ void lu_init_kernel(LuWs w) {
         w.info[b] = 0;
         w.nzb[b] = 0;
     }
+    if (w.zmap)
+        for (int i = threadIdx.x; i < 4096 / 8; i += blockDim.x) reinterpret_cast<unsigned long long*>(w.zmap + (long)b * 4096)[i] = 0ull;
 }
 
 // A wave-uniform value as a per-lane value the optimiser cannot see through: `u == 0 ? a : b` then stays a pair of
@@ -640,6 +643,7 @@ __global__ __launch_bounds__(256) void lu_u12_zero_kernel(LuWs w, int k0, int ns
     if (t == 0) {
         w.bz[b * 64 + cbi] = any;
         if (any && k0 == 0) atomicAdd(w.nzb + b, 1);
+        if (any && w.zmap) w.zmap[(long)b * 4096 + ((k0 >> 6) + 1 + cbi) * 64 + (k0 >> 6)] = 1;  // U block (rows k0 / 64, these columns)
     }
     if (any) return;
 #pragma unroll
@@ -1321,7 +1325,16 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
             const int spend = (p / w_ + 1) * w_;  // first column right of the panel that made row p a pivot row
             je = je < spend ? je : spend;
         }
-        for (int j = jbeg; j < je; ++j) O[(long)j * n + p] = A[(long)j * n + r];
+        if (w.zmap) {  // the same copy, noting which 64 x 64 blocks of the factors receive a non-zero (or a NaN)
+            unsigned char* __restrict__ zm = w.zmap + (long)b * 4096;
+            for (int j = jbeg; j < je; ++j) {
+                const double v = A[(long)j * n + r];
+                O[(long)j * n + p] = v;
+                if (v != 0.0) zm[(j >> 6) * 64 + (p >> 6)] = 1;
+            }
+        } else {
+            for (int j = jbeg; j < je; ++j) O[(long)j * n + p] = A[(long)j * n + r];
+        }
     }
 }
 

@@ -32,12 +32,18 @@ __device__ __forceinline__ double seq_sum_lds(const double* sq, int n) {
 
 // Workgroup-cooperative getrs on the right-hand side held in LDS (bs[0..n)). blockDim.x == T.
 // VEC = 2 requires n even (16-byte aligned column segments).
+// zmap (T > 256 only, may be null): the factorisation's map of 64 x 64 blocks, zmap[K * 64 + I] = 0 when block (rows I, columns
+// K) of LU holds only zeros. A sweep then leaves out the rows of such a block -- b_i -= 0 * b_k changes nothing -- unless that
+// is not exactly true: a b_k of the column block is not finite (0 * inf is NaN), or the row's b_i is -0.0 (which -0.0 - (-0.0)
+// would turn into +0.0). The factors of a banded matrix (the heat equation's Jacobian) are zero almost everywhere, and the
+// reference's solve multiplies through all of it; so did this kernel, 134 MB per system and iteration at n = 4096.
 // dg (T > 256 only): 64 x 64 doubles of LDS for the diagonal block. With few, large systems per call a workgroup's life is
 // its 2 n / 64 diagonal solves, and each of those was eight dependent round trips to memory (eight columns loaded, eight
 // steps, ...): 17 us per block at n = 4096. The block a solve needs is instead fetched by all threads while the sweep before
 // it streams (the factors are read-only), and the solve reads LDS.
 template <int VEC, int T = 256>
-__device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, double* bs, double* dg = nullptr) {
+__device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, double* bs, double* dg = nullptr,
+                                         const unsigned char* __restrict__ zmap = nullptr) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -62,6 +68,8 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         stage_store();
         __syncthreads();
     }
+    __shared__ int s_kfin;  // the entries of b the running column block multiplies with are all finite
+    auto neg_zero = [](double x) { return __double_as_longlong(x) == (long long)0x8000000000000000ull; };
 
     // ---- forward: L y = b, unit diagonal (dense.rs:188-194)
 #pragma unroll 1
@@ -89,8 +97,14 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 }
             }
             if (lane < kw) bs[i] = bi;
+            if (STAGE) {
+                const unsigned long long bad = __ballot(lane < kw && !(fabs(bi) <= 1.7976931348623157e308));
+                if (lane == 0) s_kfin = bad == 0ull;
+            }
         }
         __syncthreads();
+        const unsigned char* zk = (STAGE && zmap) ? zmap + (kb >> 6) * 64 : nullptr;
+        const bool kfin = zk != nullptr && s_kfin != 0;
         const int ibeg = kb + 64;
         if (STAGE && ibeg < n) stage_load(ibeg);  // the next diagonal block, in flight behind the sweep
         if (ibeg < n) {  // rows below a full 64-column block
@@ -99,6 +113,12 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 double acc[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = (i + v < n) ? bs[i + v] : 0.0;
+                if (kfin && zk[i >> 6] == 0) {  // a zero block of L: nothing to subtract from these rows
+                    bool nz = false;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) nz = nz || neg_zero(acc[v]);
+                    if (!nz) continue;
+                }
 #pragma unroll 1
                 for (int k = 0; k < 64; k += UNR) {
                     double lv[UNR][VEC];
@@ -158,8 +178,14 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 }
             }
             if (lane < kw) bs[i] = bi;
+            if (STAGE) {
+                const unsigned long long bad = __ballot(lane < kw && !(fabs(bi) <= 1.7976931348623157e308));
+                if (lane == 0) s_kfin = bad == 0ull;
+            }
         }
         __syncthreads();
+        const unsigned char* zk = (STAGE && zmap) ? zmap + (kb >> 6) * 64 : nullptr;
+        const bool kfin = zk != nullptr && s_kfin != 0;
         if (STAGE && kb > 0) stage_load(kb - 64);
         if (kb > 0) {
 #pragma unroll 1
@@ -167,6 +193,12 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 double acc[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = bs[i + v];
+                if (kfin && zk[i >> 6] == 0) {  // a zero block of U
+                    bool nz = false;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) nz = nz || neg_zero(acc[v]);
+                    if (!nz) continue;
+                }
 #pragma unroll 1
                 for (int k0 = kw - 1; k0 >= 0; k0 -= UNR) {
                     double uv[UNR][VEC];
@@ -259,7 +291,8 @@ template <int VEC, int T = 256>
 __global__ __launch_bounds__(T, T == 256 ? 4 : 1) void newton_iter_kernel(const double* __restrict__ LU, const int* __restrict__ perm, double* __restrict__ delta,
                                                           double* __restrict__ ee, const double* __restrict__ ewt, int n,
                                                           const int* __restrict__ idx, const double* __restrict__ scale,
-                                                          double* __restrict__ out, const int* __restrict__ skip) {
+                                                          double* __restrict__ out, const int* __restrict__ skip,
+                                                          const unsigned char* __restrict__ zmap /* or null: lu_kernels.hpp, LuWs::zmap */) {
     extern __shared__ __align__(16) double sm[];
     double* bs = sm;
     double* sq = sm + n;
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(T, T == 256 ? 4 : 1) void newton_iter_kernel(const 
     const long vb = (long)b * n;
     for (int i = t; i < n; i += T) bs[i] = -delta[vb + perm[vb + i]];  // neg_mut, then the row permutation
     __syncthreads();
-    wg_getrs<VEC, T>(LU + (long)b * n * n, n, bs, T > 256 ? sq : nullptr);  // sq (>= 4096 doubles for T > 256) is free until the solve is done
+    wg_getrs<VEC, T>(LU + (long)b * n * n, n, bs, T > 256 ? sq : nullptr, zmap ? zmap + (long)b * 4096 : nullptr);  // sq (>= 4096 doubles for T > 256) is free until the solve is done
     const double sc = scale[blockIdx.x];
     for (int i = t; i < n; i += T) {
         const double d = bs[i] * sc;  // ida_ls.rs:406-410 (sc == 1.0 exactly when cjratio == 1)

@@ -320,3 +320,47 @@ def test_entry_points_run_on_the_ctx_device_whatever_device_is_current():
     assert rc == 0 and np.array_equal(lu, lu_o) and np.array_equal(ctx.to_host(dP, (B, n), dtype=np.int64), piv_o)
     assert torch.cuda.current_device() == other
     torch.cuda.set_device(0)
+
+
+def test_newton_solve_with_zero_blocks_in_the_factors_is_exact_in_the_corner_cases():
+    """n >= 2048: the factorisation leaves a map of the factors' all-zero 64 x 64 blocks and the Newton iteration's triangular
+    solves leave such blocks out -- but only where that is exactly what the reference's arithmetic gives: not when an entry
+    of b they would multiply with is infinite or NaN, and not for a row whose entry is -0.0 (0 * b_k subtracted from -0.0 can
+    flip its sign). J = B + cj A with block-sparse A, B; right-hand sides with -0.0, an infinity, and ordinary values."""
+    import idahip
+    n, B = 2048, 3
+    rng = np.random.default_rng(20482)
+    nb = n // 64
+    Bm = np.zeros((B, n, n))
+    for s in range(B):
+        for q in range(nb):  # diagonal blocks, a sub- and a super-diagonal block here and there, one far block
+            Bm[s, q * 64:(q + 1) * 64, q * 64:(q + 1) * 64] = rng.standard_normal((64, 64)) + 8.0 * np.eye(64)
+            if q % 3 == 1:
+                Bm[s, q * 64:(q + 1) * 64, (q - 1) * 64:q * 64] = rng.standard_normal((64, 64))
+            if q % 5 == 2 and q + 1 < nb:
+                Bm[s, q * 64:(q + 1) * 64, (q + 1) * 64:(q + 2) * 64] = rng.standard_normal((64, 64))
+        Bm[s, 20 * 64:21 * 64, 3 * 64:4 * 64] = rng.standard_normal((64, 64))
+    A = np.zeros((B, n, n))
+    ctx = idahip.Ctx("linear_dense", n, B)
+    ctx.set_tolerances(1e-6, 1e-8)
+    ctx.set_linear_dense(colmajor(A), colmajor(Bm), np.zeros((B, n)))
+    ctx.upload(idahip.F_YY, np.zeros((B, n)))
+    ctx.upload(idahip.F_YP, np.zeros((B, n)))
+    rc, info = ctx.nls_lsetup(0.0, 1.0)
+    assert rc == 0 and not info.any()
+    rhs = rng.standard_normal((B, n))
+    rhs[0, 100:900] = 0.0        # the solve sees -0.0 there (the right-hand side is negated first)
+    rhs[0, 1500:1600] = -0.0     # ... and +0.0 here
+    rhs[1, 700] = np.inf         # spreads NaN / inf down the forward sweep and back up
+    rhs[2, 5 * 64:9 * 64] = 0.0
+    ctx.upload(idahip.F_DELTA, rhs)
+    ctx.upload(idahip.F_EE, np.zeros((B, n)))
+    ctx.upload(idahip.F_EWT, np.ones((B, n)))
+    ctx.newton_iter(1.0)
+    got = ctx.download(idahip.F_DELTA)
+    for s in range(B):
+        lu, piv = ctx.download_lu(s)
+        want = O.getrs(lu, piv, -rhs[s])
+        assert np.array_equal(got[s].view(np.uint64), want.view(np.uint64)) or (
+            np.array_equal(np.isnan(got[s]), np.isnan(want)) and np.array_equal(got[s][~np.isnan(want)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))), s
+    ctx.close()
