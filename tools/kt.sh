@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development tool (GPU box): rocprofv3 kernel trace of tools/panel_time.py, per-launch durations of the LU kernels.
-# usage: [IDAHIP_LIB_HIP=... IDAHIP_LU_TRAIL=...] tools/kt.sh <tag> [batch]
+# usage: [IDAHIP_LIB_HIP=...] tools/kt.sh <tag> [batch]
 TAG=$1; B=${2:-1370}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/r3/kt_$TAG
