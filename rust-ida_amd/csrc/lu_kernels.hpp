@@ -920,6 +920,11 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 template <int MAXROWS>
 __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb, int nsplit_arg) {
     constexpr int NB = 64, KC = 32;
+#ifdef IDAHIP_EXP_NOPRO
+    constexpr bool NOPRO = true;  // timing build: no gather, no U12 solve (U12 = constants); results are garbage
+#else
+    constexpr bool NOPRO = false;
+#endif
     const int nsplit = MAXROWS > 1024 ? nsplit_arg : 1;  // the row split exists for large n only
     // workgroups of one matrix: its ncb column blocks, then (nsplit > 1) nsplit - 1 helpers for each of the first
     // LU_SPLIT_BLOCKS column blocks
@@ -959,6 +964,13 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int pl = 4 * (lane & 15) + (lane >> 4);  // LDS slot of column `lane`: columns q, q+16, q+32, q+48 sit together
+#ifdef IDAHIP_STAMPS
+    unsigned long long* tst = (k0 == IDAHIP_STAMPS && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#define TSTAMP(i) do { if (tst && t == 0) tst[i] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+    TSTAMP(0);
 
 #ifndef IDAHIP_US_PAD
 #define IDAHIP_US_PAD 2
@@ -975,58 +987,6 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 
     if (MAXROWS <= 1024)
         for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
-    bool nz = false;
-    if (MAXROWS > 1024) {
-        // large n: one pivot row per lane, a column per load. Pivot rows that are neighbours in memory (a banded matrix that
-        // pivots little or not at all) then share cache lines -- 4 lines per load instead of 64 sectors; most workgroups of
-        // a banded matrix do nothing but this gather (their block turns out zero), and it bounds the launch.
-        const int pr = prow[lane];
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int cc = wave * 16 + i;
-            const double g = (cc < ncols) ? A[(long)(cb0 + cc) * n + pr] : 0.0;
-            nz = nz || (g != 0.0);
-            Us[lane][4 * (cc & 15) + (cc >> 4)] = g;
-        }
-    } else {
-#pragma unroll
-        for (int pass = 0; pass < NB / 4; ++pass) {
-            const int k = pass * 4 + wave;
-            const int pr = ldc(prow + k);
-            const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
-            nz = nz || (g != 0.0);
-            Us[k][pl] = g;
-        }
-    }
-    if (lane == 0) s_nz[wave] = 0;
-    if (__ballot(nz) != 0ull && lane == 0) s_nz[wave] = 1;
-    if (t == 0) s_anyzero = 0;
-    auto stage_l11 = [&](const int R0) {
-#pragma unroll
-        for (int i = 0; i < (KC * 64) / 256; ++i) {
-            const int e = i * 256 + t;
-            Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
-        }
-    };
-    if (MAXROWS <= 1024) stage_l11(0);
-    lds_barrier();
-    if ((s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3]) == 0) {
-        // the 64 pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
-        // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
-        if (split != 0) return;
-        double* __restrict__ O = w.out + (long)b * w.ostride;
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int cc = wave * 16 + i;
-            if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
-        }
-        return;
-    }
-    if (MAXROWS > 1024) {  // large n: most column blocks of a banded matrix have left by now, without having read these
-        for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
-        stage_l11(0);
-        lds_barrier();
-    }
     const int s0 = wave + 4 * split, sstep = 4 * nsp;  // this wave's strips: s0, s0 + sstep, ...
 
     // ---- this lane's share of a strip: rows a + 4i, columns q + 16j
@@ -1066,6 +1026,142 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             for (int i = 0; i < 4; ++i) creg[i][j] = A[coff[j] + crow[i]];
     };
 
+
+    // ---- FAST prologue (n <= 1024): U12 = L11^-1 A12 solved in registers by all four waves at once, no branch and no
+    // barrier inside the solve. Wave w owns columns 16w .. 16w+15 of the block, FOUR lanes per column: lane `part` of a
+    // quad holds rows k = 4i + part (i = 0..15) of its column. Step kk: the quad lane that owns row kk broadcasts it on
+    // the DPP crossbar (quad_perm), every lane updates its rows k > kk: a(k,j) -= a(kk,j) * l(k,kk), ascending kk, unfused
+    // (dense.rs:142-154) -- 504 updates per lane instead of 2016 on one lane of one wave. L11 (transposed, as lu_wavepanel
+    // left it) is staged once, whole, in the memory of Us -- U12 is not needed there before the solve has finished -- in a
+    // layout that gives a lane its rows as consecutive doubles (ds_read_b128, conflict-free across the quad).
+    // The path assumes that no pivot-row entry a(kk,j) is an exact zero (dense.rs:148 would leave such a column untouched,
+    // which differs from subtracting 0 * l in the sign of a zero and for a non-finite l); it checks every such entry on the
+    // way and, if one was zero, nothing has been stored: the prologue below starts over with the rule applied per entry.
+    __shared__ int s_fz[4];
+    bool fast_ok = false;
+#ifndef IDAHIP_TRAIL_QUAD
+#define IDAHIP_TRAIL_QUAD 1
+#endif
+    if constexpr (MAXROWS <= 1024 && IDAHIP_TRAIL_QUAD != 0) {
+      if (!NOPRO) {
+        const int part = lane & 3, qc = wave * 16 + (lane >> 2);
+        const bool real = qc < ncols;
+        double l11r[16], u[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l11r[i] = l11[i * 256 + t];
+        {
+            const double* __restrict__ colp = A + (long)(cb0 + (real ? qc : 0)) * n;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int p0 = ldc(prow + 4 * i), p1 = ldc(prow + 4 * i + 1), p2 = ldc(prow + 4 * i + 2), p3 = ldc(prow + 4 * i + 3);
+                const int pr = part == 0 ? p0 : part == 1 ? p1 : part == 2 ? p2 : p3;
+#ifdef IDAHIP_EXP_NOGATHER
+                u[i] = 1.0e-3 * (double)(1 + ((i + pr) & 7));  // timing build
+#else
+                u[i] = colp[pr];
+#endif
+            }
+        }
+        double* __restrict__ Lq = &Us[0][0];  // [64][66]: row kk, entry of pivot row k at (k & 3) * 16 + (k >> 2) + 2 * ((k & 3) >> 1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = i * 256 + t, kk = e >> 6, k = e & 63;
+            Lq[kk * 66 + (k & 3) * 16 + (k >> 2) + 2 * ((k & 3) >> 1)] = l11r[i];
+        }
+        if (t == 0) s_anyzero = 0;
+        lds_barrier();  // L11 and the live list are in LDS
+        TSTAMP(1);
+        if (s0 < nstrips) {  // the first strip of every wave: in flight behind the solve
+            load_C(s0);
+            load_L(s0, 0);
+        }
+        const double* __restrict__ Lp = Lq + part * 16 + 2 * (part >> 1);
+        bool anyz = false;
+        static_for<0, 64>([&](auto kt) {
+            constexpr int kk = decltype(kt)::value;
+            constexpr int p0 = kk & 3, i0 = kk >> 2;
+            const double ukk = dpp_mov_f64<p0 * 0x55, 0xf>(u[i0]);  // quad_perm: [p0, p0, p0, p0]
+            anyz = anyz || (ukk == 0.0);
+            if constexpr (p0 < 3) {  // row 4 i0 + part is below row kk for the quad's lanes part > p0 only
+                const double tn = upd(u[i0], ukk, Lp[kk * 66 + i0]);
+                u[i0] = (part > p0) ? tn : u[i0];
+            }
+            static_for<i0 + 1, 16>([&](auto it) {
+                constexpr int i = decltype(it)::value;
+                u[i] = upd(u[i], ukk, Lp[kk * 66 + i]);
+            });
+        });
+        TSTAMP(2);
+        const unsigned long long zb = __ballot(anyz && real);
+        if (lane == 0) s_fz[wave] = zb != 0ull ? 1 : 0;
+        lds_barrier();  // every wave has finished reading L11 from the memory of Us
+        fast_ok = (s_fz[0] | s_fz[1] | s_fz[2] | s_fz[3]) == 0;
+        if (fast_ok) {
+            const int qpl = 4 * (qc & 15) + (qc >> 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Us[4 * i + part][qpl] = real ? u[i] : 0.0;
+        }
+        lds_barrier();  // U12 is in Us (or nothing was written and the prologue below starts from the gather)
+        TSTAMP(3);
+      }
+    }
+    if (!fast_ok) {
+    bool nz = NOPRO;
+    if (NOPRO) {
+#pragma unroll
+        for (int pass = 0; pass < NB / 4; ++pass) Us[pass * 4 + wave][pl] = 1.0e-4 * (double)(1 + ((pass + lane) & 7));
+        if (t == 0) { s_kmask[0] = 0xffffffffu; s_kmask[1] = 0xffffffffu; s_cmask[0] = ~0ull; s_cmask[1] = ~0ull; }
+    } else if (MAXROWS > 1024) {
+        // large n: one pivot row per lane, a column per load. Pivot rows that are neighbours in memory (a banded matrix that
+        // pivots little or not at all) then share cache lines -- 4 lines per load instead of 64 sectors; most workgroups of
+        // a banded matrix do nothing but this gather (their block turns out zero), and it bounds the launch.
+        const int pr = prow[lane];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            const double g = (cc < ncols) ? A[(long)(cb0 + cc) * n + pr] : 0.0;
+            nz = nz || (g != 0.0);
+            Us[lane][4 * (cc & 15) + (cc >> 4)] = g;
+        }
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < NB / 4; ++pass) {
+            const int k = pass * 4 + wave;
+            const int pr = ldc(prow + k);
+            const double g = (lane < ncols) ? A[(long)(cb0 + lane) * n + pr] : 0.0;
+            nz = nz || (g != 0.0);
+            Us[k][pl] = g;
+        }
+    }
+    if (lane == 0) s_nz[wave] = 0;
+    if (__ballot(nz) != 0ull && lane == 0) s_nz[wave] = 1;
+    if (t == 0) s_anyzero = 0;
+    auto stage_l11 = [&](const int R0) {
+#pragma unroll
+        for (int i = 0; i < (KC * 64) / 256; ++i) {
+            const int e = i * 256 + t;
+            Ls[e >> 6][e & 63] = l11[(R0 + (e >> 6)) * NB + (e & 63)];
+        }
+    };
+    if (MAXROWS <= 1024 && !NOPRO) stage_l11(0);
+    lds_barrier();
+    if ((s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3]) == 0) {
+        // the 64 pivot rows are zero across this whole column block (banded matrices, off the band): the triangular solve
+        // leaves them as they are (a_kj == 0: column untouched, dense.rs:148) and nothing is subtracted from the rows below
+        if (split != 0) return;
+        double* __restrict__ O = w.out + (long)b * w.ostride;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cc = wave * 16 + i;
+            if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
+        }
+        return;
+    }
+    if (MAXROWS > 1024) {  // large n: most column blocks of a banded matrix have left by now, without having read these
+        for (int i = t; i < mrem; i += 256) s_live[i] = (unsigned short)live[i];
+        stage_l11(0);
+        lds_barrier();
+    }
     // one triangular stage by wave 0: rows [R0, R0+32) of U12 against the diagonal block of L11 they share
     auto trsm32 = [&](const int R0) {
         double u[KC];
@@ -1118,13 +1214,13 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
         }
     };
 
-    if (wave == 0) trsm32(0);
+    if (wave == 0 && !NOPRO) trsm32(0);
     else if (s0 < nstrips) {  // live rows only (untouched by the U12 stores), in flight behind the solves
         load_C(s0);
         load_L(s0, 0);
     }
     lds_barrier();
-    {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
+    if (!NOPRO) {   // rows 32..63 receive the updates of pivot rows 0..31: 8 rows per wave, one column per lane
         const bool zpath = s_anyzero != 0;
         double v[8];
 #pragma unroll
@@ -1151,6 +1247,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
         for (int i = 0; i < 8; ++i) Us[KC + wave * 8 + i][pl] = v[i];
     }
+    if (!NOPRO) {
     lds_barrier();
     stage_l11(KC);
     lds_barrier();
@@ -1161,7 +1258,9 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             load_L(s0, 0);
         }
     }
+    }
     lds_barrier();  // last workgroup barrier: from here on a wave touches only Us (read-only) and its own strip of Ls
+    }  // !fast_ok
     const bool slow = s_anyzero != 0;
     // The solved pivot rows are final and nothing reads them in the work matrix again: they go straight to their place in
     // the factors -- pivot k of this super-panel is row k0 + k of the reference layout, so a column's 64 entries are one
@@ -1175,6 +1274,10 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
         }
     }
+#ifdef IDAHIP_EXP_NOUPD
+    return;  // timing build: prologue only
+#endif
+    TSTAMP(4);
     const unsigned kmask0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[0]);
     const unsigned kmask1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[1]);
     if (slow && (kmask0 | kmask1) == 0u) return;  // (uniform over the workgroup) U12 of this block is all zeros: nothing to subtract
@@ -1282,7 +1385,13 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
         }
+#ifdef IDAHIP_STAMPS
+        if (s == s0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TSTAMP(5); }
+#endif
         chunk(c, 0);
+#ifdef IDAHIP_STAMPS
+        if (s == s0) TSTAMP(6);
+#endif
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];  // same wave, program order: chunk 0's reads are done
         if (s + sstep < nstrips) {  // next strip in flight behind the second chunk
@@ -1296,6 +1405,8 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             for (int i = 0; i < 4; ++i)
                 if (cok[j] && sok[i]) A[coff[j] + srow[i]] = c[i][j];
     }
+    TSTAMP(7);
+#undef TSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------ finalize

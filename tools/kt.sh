@@ -1,9 +1,9 @@
 #!/bin/bash
 # Development tool (GPU box): rocprofv3 kernel trace of tools/panel_time.py, per-launch durations of the LU kernels.
-# usage: [IDAHIP_LIB_HIP=...] tools/kt.sh <tag> [batch]
-TAG=$1; B=${2:-1370}
+# usage: [IDAHIP_LIB_HIP=...] tools/kt.sh <tag> [batch] [round-dir, default r4]
+TAG=$1; B=${2:-1370}; RD=${3:-r4}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/r3/kt_$TAG
+OUT=$ROOT/gpurun_out/$RD/kt_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 IDAHIP_GEN_PROCS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT -o kt --output-format csv -- python3 $ROOT/tools/panel_time.py $B > $OUT/log.txt 2>&1
