@@ -232,7 +232,8 @@ class Runner:
         self.ctx.timing(0)
         c = ens.counters()
         out = {"seconds": dt, "iters": ens.total_newton_iters(), "rounds": ens.total_rounds(), "tim": tim,
-               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy()}
+               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy(),
+               "paths": {k: int(c[k].sum()) for k in ("ncfn", "nls_nconvfails", "nlufail", "nconv_jcur", "nfail_first", "nge")}}
         ens.close()
         self.ctx.set_lu_variant(4)
         return out
@@ -390,7 +391,15 @@ def main():
         # the same passes with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
         # device-side convergence tests (first slice); identical work and results, only the pace changes
         unfused_rates = [(lambda p: p["iters"] / p["seconds"])(run.whole_pass(4, fused=0, device_ctl=0)) for _ in range(3)]
+        pth = passes[0]["paths"]
         extras = {
+            "reference_text_paths": {
+                "sum_ncfn": pth["ncfn"], "sum_newton_internal_resetups": pth["nls_nconvfails"], "lu_failures_Q2": pth["nlufail"],
+                "newton_gave_up_with_current_jacobian_Q3_Q4": pth["nconv_jcur"], "failed_attempts_before_first_step_Q5": pth["nfail_first"],
+                "root_function_evaluations": pth["nge"], "root_returns": 0,
+                "note": "sums over the batch of one whole pass: how often a system took a path on which oracle and product follow C IDA "
+                        "where the reference's text does otherwise (SURVEY.md 9, DESIGN.md 2); zero = the deviation is not exercised by this "
+                        "configuration (Newton-internal re-setups follow the reference's text: newton.rs:146-152); no root functions are set"},
             "whole_pass": {"value": statistics.median(rates), "unit": "Newton iters/s", "passes": [round(r, 1) for r in rates],
                            "newton_iters_per_pass": passes[0]["iters"], "rounds_per_pass": passes[0]["rounds"],
                            "seconds_median": statistics.median(p["seconds"] for p in passes),

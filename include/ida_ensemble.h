@@ -111,7 +111,11 @@ int idaens_stream(idaens* e, const double* touts, int ntout, long max_rounds, lo
 enum {
     IDAENS_C_NST = 0, IDAENS_C_NRE = 1, IDAENS_C_NJE = 2, IDAENS_C_NSETUPS = 3, IDAENS_C_NNI = 4, IDAENS_C_NETF = 5,
     IDAENS_C_NCFN = 6, IDAENS_C_NATTEMPTS = 7, IDAENS_C_NLS_NCONVFAILS = 8, IDAENS_C_KUSED = 9, IDAENS_C_KK = 10,
-    IDAENS_C_NGE = 11 /* root-function evaluations (ida_nge) */
+    IDAENS_C_NGE = 11 /* root-function evaluations (ida_nge) */,
+    /* times the system took a path on which this library follows C IDA and not the reference's text:      */
+    IDAENS_C_NLUFAIL = 12 /* Q2: zero pivot reported by the factorisation, treated as recoverable                          */,
+    IDAENS_C_NCONV_JCUR = 13 /* Q3/Q4: Newton's ConvergenceRecover with a current Jacobian, treated as recoverable          */,
+    IDAENS_C_NFAIL_FIRST = 14 /* Q5: failed attempts before the first step (reset() rescales phi[1] only)                   */
 };
 int idaens_get_counter(const idaens* e, int which, int64_t* out);
 enum { IDAENS_R_TN = 0, IDAENS_R_HUSED = 1, IDAENS_R_HH = 2, IDAENS_R_H0U = 3, IDAENS_R_TOLSF = 4 };

@@ -577,19 +577,26 @@ int attempt_round(idaens* e, std::vector<int32_t>& act, SolveCall& C) {
     std::vector<Sys>& S = e->sys;
     const int na = (int)act.size();
     // --- step() prologue + set_coeffs + tn += hh (lib.rs:619-653)
-    std::vector<int32_t> kkns(2 * (size_t)na);
-    std::vector<double> beta(MXORDP1 * (size_t)na), gamma(MXORDP1 * (size_t)na);
+    // A system the device lock-step stepper left inside an attempt whose Newton solve must start over with a linear setup
+    // (newton_retry: round_ida.hpp's round_newton_ctl_kernel, "in the next round") has had its begin_attempt and its prediction:
+    // here it only joins the Newton solve, with call_lsetup set (a round-limited device call followed by a host-stepper call).
+    std::vector<int32_t> pred, kkns;
+    std::vector<double> beta, gamma;
     for (int q = 0; q < na; ++q) {
         Sys& s = S[act[q]];
-        begin_attempt(s);  // step() prologue, set_coeffs, tn += hh, lsetup decision (ida_controller.hpp)
-        kkns[2 * q] = s.kk;
-        kkns[2 * q + 1] = s.ns;
-        for (int j = 0; j < MXORDP1; ++j) {
-            beta[MXORDP1 * q + j] = s.beta[j];
-            gamma[MXORDP1 * q + j] = s.gamma[j];
+        if (s.newton_retry) {
+            s.newton_retry = false;
+            s.call_lsetup = true;
+            continue;
         }
+        begin_attempt(s);  // step() prologue, set_coeffs, tn += hh, lsetup decision (ida_controller.hpp)
+        pred.push_back(act[q]);
+        kkns.push_back(s.kk);
+        kkns.push_back(s.ns);
+        beta.insert(beta.end(), s.beta, s.beta + MXORDP1);
+        gamma.insert(gamma.end(), s.gamma, s.gamma + MXORDP1);
     }
-    ENS_CALL(e, idahip_predict(e->ctx, kkns.data(), beta.data(), gamma.data(), act.data(), na));
+    if (!pred.empty()) ENS_CALL(e, idahip_predict(e->ctx, kkns.data(), beta.data(), gamma.data(), pred.data(), (int)pred.size()));
 
     // --- Newton
     int rc = newton_solve_batched(e, act);
@@ -1244,6 +1251,9 @@ int idaens_get_counter(const idaens* e, int which, int64_t* out) {
             case IDAENS_C_KUSED: v = s.kused; break;
             case IDAENS_C_KK: v = s.kk; break;
             case IDAENS_C_NGE: v = s.nge; break;
+            case IDAENS_C_NLUFAIL: v = s.nlufail; break;
+            case IDAENS_C_NCONV_JCUR: v = s.nconv_jcur; break;
+            case IDAENS_C_NFAIL_FIRST: v = s.nfail_first; break;
             default: return -2;
         }
         out[b] = v;

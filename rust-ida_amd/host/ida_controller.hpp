@@ -81,6 +81,10 @@ struct SysCore {
     double phi0nrm = 0.0;  // ||phi[0]||_wrms(ewt) for the next step's tolsf test
     bool ewt_bad = false;
     long n_attempts = 0;
+    // how often this system took a path on which oracle and product follow C IDA instead of the reference's text:
+    long nlufail = 0;      // Q2: the factorisation reported a zero pivot (the reference unwraps: panic)
+    long nconv_jcur = 0;   // Q3/Q4: Newton gave up with a current Jacobian (reference: loops / treats it as fatal)
+    long nfail_first = 0;  // Q5: a failed attempt while nst == 0 (reference's reset() rescales all of phi)
     int status = 0;
     double tret = 0.0;
     bool dead = false;  // a fatal IdaError was returned: later solve calls report it again
@@ -239,6 +243,9 @@ IDA_HD inline void restore_scalars(SysCore& s) {
 // ---------------------------------------------------------------- handle_n_flag (lib.rs:1120-1244); 0 = predict again
 IDA_HD inline int handle_n_flag(SysCore& s, int nflag, double err_k, double err_km1, long maxnef, long maxncf) {
     s.phase = 1;
+    if (s.nst == 0) s.nfail_first += 1;
+    if (nflag == NFLAG_LSETUP_RECVR) s.nlufail += 1;
+    if (nflag == NFLAG_CONV_RECVR) s.nconv_jcur += 1;
     if (nflag == NFLAG_TEST_FAIL) {
         s.nef += 1;
         s.netf += 1;

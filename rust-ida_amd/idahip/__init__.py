@@ -397,7 +397,7 @@ class Ctx:
 
 
 COUNTERS = {"nst": 0, "nre": 1, "nje": 2, "nsetups": 3, "nni": 4, "netf": 5, "ncfn": 6, "n_attempts": 7, "nls_nconvfails": 8,
-            "kused": 9, "kk": 10, "nge": 11}
+            "kused": 9, "kk": 10, "nge": 11, "nlufail": 12, "nconv_jcur": 13, "nfail_first": 14}
 REALS = {"tn": 0, "hused": 1, "hh": 2, "h0u": 3, "tolsf": 4}
 
 

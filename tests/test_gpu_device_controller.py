@@ -180,3 +180,30 @@ def test_device_lock_step_schedule_outputs_resume_and_stream():
             assert pd == ph
             same(state(d2), state(h2))
     assert pd > 0
+
+
+@pytest.mark.parametrize("n,batch", [(48, 20), (200, 6)])
+def test_switching_steppers_between_round_limited_calls(n, batch):
+    """A round-limited call of the device lock-step stepper can leave a system INSIDE an attempt whose Newton solve has to
+    start over with a linear setup in the next round (newton_retry, round_ida.hpp). The next call may run on the host stepper
+    (idaens_set_device_controller(0), roots, tracing ...): it must continue that attempt -- not begin it again. One round per
+    call, the stepper alternating from call to call, against both steppers run alone."""
+    from idahip import problems
+    prob = problems.linear_dense(n=n, batch=batch, procs=1)
+    touts = prob["touts"]
+    cd, dev = make(prob, 1)
+    sd, td, rd, yd, ypd = dev.solve_schedule(touts, outputs=True)
+    assert (sd == 0).all()
+    cm, mix = make(prob, 1)
+    ym = np.full_like(yd, np.nan)
+    for i in range(4000):
+        mix.set_device_controller(1 if i % 2 == 0 else 0)
+        s, t, r, yo, ypo = mix.solve_schedule(touts, max_rounds=1, outputs=True)
+        m = ~np.isnan(yo)
+        ym[m] = yo[m]
+        if (s != 99).all():
+            break
+    assert (s == 0).all() and np.array_equal(ym, yd)
+    same(state(mix), state(dev))
+    # the path is only exercised if some Newton solve did start over: say so in the test's output
+    print("Newton-internal re-setups in this run:", int(dev.counter("nls_nconvfails").sum()))
