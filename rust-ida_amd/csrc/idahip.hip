@@ -453,7 +453,7 @@ int launch_sys(idahip_ctx* c, const SysArgs& a, int nsys, double* jac_out, const
 
 // Jacobian kernels of IdaNLProblem::setup (jac at the current yy, yp, cj) into the LU work matrix
 int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj, int nsys, const double* hTn = nullptr,
-               const double* hCj = nullptr, const int32_t* hIdx = nullptr) {
+               const double* hCj = nullptr, const int32_t* hIdx = nullptr, const int* d_skip = nullptr) {
     const int n = c->n;
     const long nn = (long)n * n;
     switch (c->kind) {
@@ -477,7 +477,7 @@ int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj
         case IDAHIP_HEAT1D: {
             int chunks = 1;
             while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
-            hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks);
+            hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks, d_skip);
             break;
         }
     }
@@ -1055,8 +1055,11 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     if (!c) return -1;
     if (!hSys || !call || !hRoundsDone || !hAcc || !rounds_run || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
     if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
-    if (c->n <= TINY_N || c->n > LU_MAX_N || c->kind != IDAHIP_LINEAR_DENSE || c->lu_variant < 4)
-        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d (LU variant 4)", TINY_N, LU_MAX_N);
+    const bool lin = c->kind == IDAHIP_LINEAR_DENSE && c->n <= LU_MAX_N;
+    const bool heat = c->kind == IDAHIP_HEAT1D && c->n <= LU_BIG_MAX_N;
+    if (c->n <= TINY_N || !(lin || heat) || c->lu_variant < 4)
+        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d and heat problems with n <= %d (LU variant 4)",
+                    TINY_N, LU_MAX_N, LU_BIG_MAX_N);
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;
@@ -1083,6 +1086,7 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     a.yout = hYout ? c->tiny_yout : nullptr;
     a.ypout = hYPout ? c->tiny_ypout : nullptr;
     a.round_base = call->round_base;
+    a.fused_jac = c->kind == IDAHIP_LINEAR_DENSE ? 1 : 0;
     int* ib = c->rnd_i;
     a.stepping = ib; a.in_newton = ib + batch; a.skipP = ib + 2 * batch; a.skipL = ib + 3 * batch; a.skipI = ib + 4 * batch;
     a.skipS = ib + 5 * batch; a.ident = ib + 6 * batch; a.lu_list = ib + 7 * batch; a.lu_cnt = ib + 8 * batch; a.summary = ib + 8 * batch + 1;
@@ -1114,10 +1118,18 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
             sa.reset_ee = 1; sa.skip = a.skipP;
             if ((rc = launch_sys(c, sa, batch, nullptr))) return rc;
         }
-        {
+        if (c->kind == IDAHIP_LINEAR_DENSE) {
             KTimer kt(c, IDAHIP_K_SYS_JAC, 0);
             sa.skip = a.skipL;
             if ((rc = launch_sys(c, sa, batch, c->jw))) return rc;
+        } else {  // no fused residual + Jacobian kernel for this problem: the residual, then the Jacobian of the same systems
+            {
+                KTimer kt(c, IDAHIP_K_SYS, 0);
+                sa.skip = a.skipL;
+                if ((rc = launch_sys(c, sa, batch, nullptr))) return rc;
+            }
+            KTimer kt(c, IDAHIP_K_JAC, 0);
+            if ((rc = launch_jac(c, c->jw, a.ident, a.cj, batch, nullptr, nullptr, nullptr, a.skipL))) return rc;
         }
         {
             KTimer kt(c, IDAHIP_K_LU, 0);

@@ -10,7 +10,8 @@ namespace idahip {
 // (reference layout: rows at their pivoted positions). 64-column super-panels; per super-panel the panel factorisation
 // (by live rows: > 1024 lu_panelr, > 512 or variant 3 lu_panel2 + narrow update, else lu_wavepanel) and one launch of the
 // rank-64 trailing kernel; a final row scatter.
-// d_cnt (optional): the list's length lives on the device and nsys is only its upper bound (n <= LU_MAX_N, variant 4).
+// d_cnt (optional): the list's length lives on the device and nsys is only its upper bound (variant 4): every kernel's
+// surplus workgroups leave on reading it.
 inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* out, long ostride, long long* piv, long pstride,
                              int* perm, const int* d_idx, int nsys, const int* d_cnt = nullptr) {
     const int n = c->n;
@@ -22,7 +23,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         return 0;
     }
     if (n > LU_BIG_MAX_N) return fail(c, -3, "blocked LU supports n <= %d in this build (n = %d)", LU_BIG_MAX_N, n);
-    if (d_cnt && (n > LU_MAX_N || c->lu_variant < 4)) return fail(c, -3, "a device-side list length needs the wave-per-matrix pipeline (n <= %d)", LU_MAX_N);
+    if (d_cnt && c->lu_variant < 4) return fail(c, -3, "a device-side list length needs LU variant 4");
     LuWs w;
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.cnt = d_cnt; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;
@@ -115,7 +116,9 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 // blocks have work, and leave at once otherwise.
                 const int nstrips = (ntrail + 15) / 16;
                 int nsplit = nstrips >= 64 ? 8 : nstrips >= 32 ? 4 : nstrips >= 16 ? 2 : 1;
-                while (nsplit > 1 && nsys * nsplit > 512) nsplit >>= 1;  // two workgroups per CU: the helpers must not queue behind each other
+                // two workgroups per CU: the helpers must not queue behind each other. (With the list's length on the device the
+                // kernel makes the same reduction from the count it reads; the launch then carries the helpers of the largest split.)
+                while (!d_cnt && nsplit > 1 && nsys * nsplit > 512) nsplit >>= 1;
                 const int nbs = nsplit > 1 ? std::min(ncb, LU_SPLIT_BLOCKS) : 0;
                 // first the column blocks whose 64 pivot rows are zero (off the band): found, and their U12 written, by a light
                 // kernel at full occupancy; the update kernel's workgroups for them leave at once

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
     constexpr int NW = MAXT / 64;
     constexpr int LDR = NB + 2;  // row slot: NB entries, [NB] = 1/pivot
     static_assert(NW <= 16 && NB <= 64, "candidate scan assumes <= 16 waves, zero mask assumes NB <= 64");
+    if (w.cnt && (int)blockIdx.x >= ldc(w.cnt)) return;  // (list length on the device: surplus workgroups leave)
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
 __global__ __launch_bounds__(256) void lu_u12_zero_kernel(LuWs w, int k0, int nsys, int ncb) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cbi = slot % ncb, mi = (slot / ncb) * 8 + xcd;  // same dealing as lu_trail64w_kernel
-    if (mi >= nsys) return;
+    if (mi >= (w.cnt ? ldc(w.cnt) : nsys)) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
     const int n = w.n;
@@ -949,7 +950,12 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     if (nsplit > 1) {
         const int nzb = ldc(w.nzb + b);
         const bool banded = k0 > 0 && nzb * 4 <= (w.n - 1) / 64;
-        if (banded && cbi < nzb && cbi < nbs) nsp = nsplit;
+        int eff = nsplit;  // helpers in use: as many as keep the launch at two workgroups per CU (lu_driver.hpp)
+        if (w.cnt) {
+            const int cntv = ldc(w.cnt);
+            while (eff > 1 && cntv * eff > 512) eff >>= 1;
+        }
+        if (banded && cbi < nzb && cbi < nbs && split < eff) nsp = eff;
         else if (split != 0) return;
     }
     const int n = w.n;

@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* 
 }
 
 __global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats, int n, const double* __restrict__ params,
-                                                       const int* __restrict__ idx, const double* __restrict__ cjs, int chunks) {
+                                                       const int* __restrict__ idx, const double* __restrict__ cjs, int chunks,
+                                                       const int* __restrict__ skip) {
+    if (skip && skip[blockIdx.x] != 0) return;  // (the device lock-step stepper's per-system flags)
     const int b = idx[blockIdx.x];
     const double cj = cjs[blockIdx.x];
     const double coef = params[b];

@@ -1,4 +1,4 @@
-// Device-resident LOCK-STEP stepper for larger systems (8 < n <= 512, device residual): a round = one step attempt of every
+// Device-resident LOCK-STEP stepper for larger systems (8 < n <= 1024 linear dense, n <= 4096 heat; device residual): a round = one step attempt of every
 // system that is stepping, as in host/ensemble_ida.cpp -- but the scalar controller of every system lives on the device, the
 // index lists are built there, and the host only enqueues the round's fixed sequence of launches. No host round trip inside a
 // round; in throughput mode (idaens_stream, a fixed number of rounds) none at all between rounds.
@@ -31,6 +31,7 @@ struct RoundArgs {
     long long round_base;   // rounds completed before this launch sequence started
     long long round;        // index of this round within the call
     int first_round;        // systems enter the call in this round
+    int fused_jac;          // the problem has a fused residual + Jacobian kernel (linear dense); otherwise two launches serve a setup
     // per-system round state (device arrays of length batch)
     int* stepping;          // the system takes step attempts
     int* in_newton;         // the system's Newton solve is under way in this round
@@ -248,7 +249,12 @@ __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
         if (kind != 0) a.rounds_done[b] += 1;
         if (kind == 1) atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
         if (kind == 2) {
-            atomicAdd(&a.stats[IDAHIP_K_SYS_JAC], 1ull);
+            if (a.fused_jac) {
+                atomicAdd(&a.stats[IDAHIP_K_SYS_JAC], 1ull);
+            } else {
+                atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
+                atomicAdd(&a.stats[IDAHIP_K_JAC], 1ull);
+            }
             atomicAdd(&a.stats[IDAHIP_K_LU], 1ull);
         }
     }

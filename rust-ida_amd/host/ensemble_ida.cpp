@@ -869,6 +869,7 @@ int device_ctl_applies(const idaens* e, const SolveCall& C) {
     if (!e->device_ctl || e->nrtfn != 0 || C.itask != IDAENS_NORMAL || e->trace_sys >= 0) return 0;
     if (e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63)) return 1;
     if (e->n > 8 && e->n <= 1024 && k == IDAHIP_LINEAR_DENSE && idahip_lu_variant(e->ctx) >= 4) return 2;
+    if (e->n > 8 && e->n <= 4096 && k == IDAHIP_HEAT1D && idahip_lu_variant(e->ctx) >= 4) return 2;
     return 0;
 }
 

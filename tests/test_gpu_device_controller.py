@@ -207,3 +207,28 @@ def test_switching_steppers_between_round_limited_calls(n, batch):
     same(state(mix), state(dev))
     # the path is only exercised if some Newton solve did start over: say so in the test's output
     print("Newton-internal re-setups in this run:", int(dev.counter("nls_nconvfails").sum()))
+
+
+@pytest.mark.parametrize("n,batch,ntout", [(40, 6, 10), (700, 3, 3), (1100, 3, 2), (4096, 4, 2)])
+def test_device_lock_step_rounds_for_the_heat_problem(n, batch, ntout):
+    """Config 4's problem on the device lock-step stepper (idahip_round_solve with the heat kernels; above 1024 rows the batched LU
+    takes its workgroup-per-matrix panel kernels, the zero-block kernel and the helper workgroups with the list's length read on
+    the device): per system the same steps as the host stepper and the oracle, every counter, at every output."""
+    from idahip import problems
+    prob = problems.heat1d(n=n, batch=batch)
+    touts = [float(t) for t in prob["touts"][:ntout]]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    ref = O.run_ensemble("heat1d", n, prob["yy0"], prob["yp0"], prob["rtol"], prob["atol"], touts, params=prob["params"], nthreads=batch)
+    assert (ref["status"] == 0).all()
+    for i, t in enumerate(touts):
+        sd, td = dev.solve(t)
+        sh, th = host.solve(t)
+        assert (sd == 0).all() and np.array_equal(sd, sh) and np.array_equal(td, th)
+        same(state(dev), state(host))
+        assert np.array_equal(dev.yy(), ref["yy"][i]) and np.array_equal(dev.yp(), ref["yp"][i]), i
+    c = dev.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(c["kused"], ref["kused"]) and np.array_equal(dev.real("hused"), ref["hused"])
+    assert dev.total_rounds() >= host.total_rounds() > 0
