@@ -283,7 +283,12 @@ where
     }
 
     fn get_type(&self) -> LSolverType {
-        LSolverType::Direct
+        // the library states its solver's type (include/ida_hip.h: idahip_ls_type); idaLsSolve branches on it (src/ida_ls.rs:316)
+        match unsafe { sys::idahip_ls_type(self.ctx.as_raw()) } {
+            1 => LSolverType::Iterative,
+            2 => LSolverType::MatrixIterative,
+            _ => LSolverType::Direct,
+        }
     }
 
     fn setup<S>(&mut self, mat_a: &mut Matrix<f64, D, D, S>) -> Result<(), linear::Error>

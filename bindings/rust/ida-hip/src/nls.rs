@@ -22,7 +22,8 @@ const RATEMAX: f64 = 0.9; // src/ida_nls.rs:15
 /// `toldel`, `eps_newt` before a nonlinear solve exactly as `Ida::nonlinear_solve` does (src/lib.rs:787-812), after uploading
 /// `yypredict`, `yppredict` and `ewt` (`Ctx::upload`).
 pub struct HipNlsProblem<D: DimName> {
-    pub ctx: Ctx,
+    /// private: `d_x` / `d_w` below were allocated on this context and `Drop` frees them through it
+    ctx: Ctx,
     pub tn: f64,
     pub cj: f64,
     pub cjold: f64,
@@ -49,6 +50,11 @@ impl<D: DimName> HipNlsProblem<D> {
         let (d_x, d_w) = unsafe { (sys::idahip_dev_alloc(raw, bytes) as *mut c_double, sys::idahip_dev_alloc(raw, bytes) as *mut c_double) };
         assert!(!d_x.is_null() && !d_w.is_null(), "device allocation failed");
         HipNlsProblem { ctx, tn: 0.0, cj: 0.0, cjold: 0.0, cjratio: 1.0, ss: 20.0, oldnrm: 0.0, toldel: 0.0, eps_newt: 0.0, nre: 0, nsetups: 0, d_x, d_w, _dim: PhantomData }
+    }
+
+    /// The device context (read-only: the problem's device buffers belong to it).
+    pub fn ctx(&self) -> &Ctx {
+        &self.ctx
     }
 
     fn upload_field(&mut self, field: i32, v: &[f64]) -> Result<(), Error> {

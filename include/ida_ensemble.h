@@ -65,8 +65,12 @@ int idaens_set_fused_newton(idaens* e, int on);
  *     round -- one synchronisation per round, none in idaens_stream (idahip_round_solve). A Newton solve that has to start
  *     over with a fresh Jacobian does so in the next round, so a system may need one round more than with the host stepper;
  *     its steps, orders, counters and results are the same.
+ *   - the heat problem with 8 < n <= 4096: the same lock-step rounds (the batched LU of n > 1024 takes every list length from
+ *     the device).
  * off: the lock-step host stepper for every problem. Same results either way (one controller source, pow with glibc's
- * bits); the switch is the A/B. */
+ * bits); the switch is the A/B. idaens_create compares the device pow with this host's std::pow on the controller's argument
+ * ranges once per process: if they differ (another libm than the one glibc_pow.hpp restates) the device steppers stay off,
+ * idaens_last_error says so and this call returns 1 for on != 0. */
 int idaens_set_device_controller(idaens* e, int on);
 /* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
  * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call
@@ -115,7 +119,9 @@ enum {
     /* times the system took a path on which this library follows C IDA and not the reference's text:      */
     IDAENS_C_NLUFAIL = 12 /* Q2: zero pivot reported by the factorisation, treated as recoverable                          */,
     IDAENS_C_NCONV_JCUR = 13 /* Q3/Q4: Newton's ConvergenceRecover with a current Jacobian, treated as recoverable          */,
-    IDAENS_C_NFAIL_FIRST = 14 /* Q5: failed attempts before the first step (reset() rescales phi[1] only)                   */
+    IDAENS_C_NFAIL_FIRST = 14 /* Q5: failed attempts before the first step (reset() rescales phi[1] only)                   */,
+    IDAENS_C_NLI = 15 /* idaLsSolve: linear iterations (0 with a direct LSolver, src/ida_ls.rs:389-400) */,
+    IDAENS_C_NCFL = 16 /* idaLsSolve: linear convergence failures (src/ida_ls.rs:413-415) */
 };
 int idaens_get_counter(const idaens* e, int which, int64_t* out);
 enum { IDAENS_R_TN = 0, IDAENS_R_HUSED = 1, IDAENS_R_HH = 2, IDAENS_R_H0U = 3, IDAENS_R_TOLSF = 4 };

@@ -101,6 +101,14 @@ int idahip_memcpy_d2h(idahip_ctx* ctx, void* h, const void* d, size_t bytes);
 int idahip_ls_setup(idahip_ctx* ctx, double* dA, int64_t* dPiv, int32_t* hInfo, const int32_t* hIdx, int nsys);
 int idahip_ls_solve(idahip_ctx* ctx, const double* dLU, const int64_t* dPiv, double* dX, const double* dB, double tol,
                     const int32_t* hIdx, int nsys);
+/* LSolver::get_type (crates/linear/src/traits.rs:36-38, LSolverType: crates/linear/src/lib.rs:15-20): what idaLsSolve branches on
+ * (src/ida_ls.rs:316-329, 387-410: the tolerance handed to the solver, which vector is copied to b, whether the 2/(1+cjratio)
+ * scaling applies, the nli / ncfl counters). This library's solver is the dense direct one: IDAHIP_LS_DIRECT, no iterations,
+ * no residual norm (Dense::num_iters / res_norm, traits.rs:82-90); the host stepper's bookkeeping takes the type from here. */
+typedef enum { IDAHIP_LS_DIRECT = 0, IDAHIP_LS_ITERATIVE = 1, IDAHIP_LS_MATRIX_ITERATIVE = 2 } idahip_ls_kind;
+int idahip_ls_type(const idahip_ctx* ctx);
+int idahip_ls_num_iters(const idahip_ctx* ctx);
+double idahip_ls_res_norm(const idahip_ctx* ctx);
 /* NormRms::norm_wrms (src/norm_rms.rs:31-38): hOut[s] = sqrt(sum_i (x_i w_i)^2 / n), summed left to right */
 int idahip_wrms(idahip_ctx* ctx, const double* dX, const double* dW, double* hOut, const int32_t* hIdx, int nsys);
 

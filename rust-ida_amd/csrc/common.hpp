@@ -89,7 +89,9 @@ struct idahip_ctx {
     idahip_jac_fn cb_jac = nullptr;
     void* cb_user = nullptr;
     double* cb_stage = nullptr;                       // [batch][3][n] device staging of yy, yp, res of the listed systems
-    std::vector<double> cb_host;                      // host mirror of cb_stage, and the Jacobian of one system
+    std::vector<double> cb_host;                      // host mirror of cb_stage
+    double *cb_jpin = nullptr, *cb_jdev = nullptr;    // pinned / device staging of a chunk of user Jacobians (lazy)
+    size_t cb_jcap = 0;                               // systems the two staging buffers hold
 
     // staging ring
     idahip::Slot slots[idahip::NSLOT];

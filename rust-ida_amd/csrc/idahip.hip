@@ -143,6 +143,8 @@ int idahip_destroy(idahip_ctx* c) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->rnd_host) (void)hipHostFree(c->rnd_host);
+    if (c->cb_jpin) (void)hipHostFree(c->cb_jpin);
+    if (c->cb_jdev) (void)hipFree(c->cb_jdev);
     for (int i = 0; i < NSLOT; ++i) {
         if (c->slots[i].h) (void)hipHostFree(c->slots[i].h);
         if (c->slots[i].d) (void)hipFree(c->slots[i].d);
@@ -406,17 +408,40 @@ int callback_jac(idahip_ctx* c, double* work, const int* d_idx, const double* hT
     const size_t cnt = (size_t)nsys * 3 * n;
     hipLaunchKernelGGL(callback_pack_kernel, dim3(nsys), dim3(256), 0, c->stream, (const double*)c->yy, (const double*)c->yp,
                        (const double*)c->savres, d_idx, n, c->cb_stage);
-    if (c->cb_host.size() < cnt + nn) c->cb_host.resize(cnt + nn);
+    if (c->cb_host.size() < cnt) c->cb_host.resize(cnt);
     double* h = c->cb_host.data();
-    double* J = h + cnt;
+    // The Jacobians go up a chunk at a time: the user's function fills a pinned buffer system by system, ONE asynchronous copy
+    // takes the chunk to a device staging buffer and one kernel scatters it into the listed systems' work matrices (a pageable
+    // hipMemcpy per system on the null stream before: O(nsys) blocking copies per setup). A chunk is <= 64 MB.
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nsys, ((size_t)64 << 20) / (nn * sizeof(double))));
+    if (c->cb_jcap < chunk) {
+        if (c->cb_jpin) (void)hipHostFree(c->cb_jpin);
+        if (c->cb_jdev) (void)hipFree(c->cb_jdev);
+        c->cb_jpin = nullptr; c->cb_jdev = nullptr; c->cb_jcap = 0;
+        if (hipHostMalloc((void**)&c->cb_jpin, chunk * nn * sizeof(double)) != hipSuccess) { c->cb_jpin = nullptr; return fail(c, -100, "pinned staging for %zu Jacobians", chunk); }
+        if (hipMalloc((void**)&c->cb_jdev, chunk * nn * sizeof(double)) != hipSuccess) {
+            (void)hipHostFree(c->cb_jpin);
+            c->cb_jpin = nullptr; c->cb_jdev = nullptr;
+            return fail(c, -100, "device staging for %zu Jacobians", chunk);
+        }
+        c->cb_jcap = chunk;
+    }
     IDAHIP_HIP(c, hipMemcpyAsync(h, c->cb_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
     IDAHIP_HIP(c, hipStreamSynchronize(c->stream));
-    for (int s = 0; s < nsys; ++s) {
-        const double* hs = h + (size_t)s * 3 * n;
-        for (size_t e = 0; e < nn; ++e) J[e] = 0.0;  // J <- 0 (ida_ls.rs:255)
-        if (c->cb_jac(hIdx[s], hTn[s], hCj[s], hs, hs + n, hs + 2 * n, J, c->cb_user) != 0)
-            return fail(c, -7, "the user's Jacobian function failed for system %d", hIdx[s]);
-        IDAHIP_HIP(c, hipMemcpy(work + (size_t)hIdx[s] * nn, J, sizeof(double) * nn, hipMemcpyHostToDevice));
+    for (size_t s0 = 0; s0 < (size_t)nsys; s0 += chunk) {
+        const size_t m = std::min(chunk, (size_t)nsys - s0);
+        for (size_t q = 0; q < m; ++q) {
+            const size_t s = s0 + q;
+            const double* hs = h + s * 3 * n;
+            double* J = c->cb_jpin + q * nn;
+            for (size_t e = 0; e < nn; ++e) J[e] = 0.0;  // J <- 0 (ida_ls.rs:255)
+            if (c->cb_jac(hIdx[s], hTn[s], hCj[s], hs, hs + n, hs + 2 * n, J, c->cb_user) != 0)
+                return fail(c, -7, "the user's Jacobian function failed for system %d", hIdx[s]);
+        }
+        IDAHIP_HIP(c, hipMemcpyAsync(c->cb_jdev, c->cb_jpin, sizeof(double) * m * nn, hipMemcpyHostToDevice, c->stream));
+        const int gy = (int)std::min<size_t>(64, (nn + 255) / 256);
+        hipLaunchKernelGGL(callback_scatter_jac_kernel, dim3((unsigned)m, gy), dim3(256), 0, c->stream, (const double*)c->cb_jdev, work, d_idx + s0, (long)nn);
+        if (s0 + chunk < (size_t)nsys) IDAHIP_HIP(c, hipStreamSynchronize(c->stream));  // the pinned buffer is filled again
     }
     return 0;
 }
@@ -1024,13 +1049,13 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
 static int stepper_buffers(idahip_ctx* c, const idahip_tiny_call* call, bool outputs) {
     const int batch = c->batch, n = c->n;
     int rc = 0;
-    if (!c->tiny_sys) {
-        IDAHIP_HIP(c, hipMalloc(&c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore)));
-        rc |= dalloc(c, &c->tiny_start, (size_t)batch);
-        rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
-        rc |= dalloc(c, &c->tiny_acc, (size_t)2);
-        if (rc) return rc;
-    }
+    // (each buffer is guarded by itself: a failed allocation must not leave a later call with one non-null pointer that
+    // stands for the whole group)
+    if (!c->tiny_sys) IDAHIP_HIP(c, hipMalloc(&c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore)));
+    if (!c->tiny_start) rc |= dalloc(c, &c->tiny_start, (size_t)batch);
+    if (!c->tiny_rounds) rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
+    if (!c->tiny_acc) rc |= dalloc(c, &c->tiny_acc, (size_t)2);
+    if (rc) return rc;
     if (call->ntout > c->tiny_ntout_cap) {
         if (c->tiny_touts) (void)hipFree(c->tiny_touts);
         c->tiny_touts = nullptr;
@@ -1066,12 +1091,10 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     const long nn = (long)n * n;
     int rc = stepper_buffers(c, call, hYout || hYPout);
     if (rc) return rc;
-    if (!c->rnd_i) {
-        rc |= dalloc(c, &c->rnd_i, (size_t)8 * batch + 6 + 2 * IDAHIP_K_COUNT);
-        rc |= dalloc(c, &c->rnd_d, (size_t)4 * batch);
-        if (rc) return rc;
-        IDAHIP_HIP(c, hipHostMalloc((void**)&c->rnd_host, 4 * sizeof(int32_t)));
-    }
+    if (!c->rnd_i) rc |= dalloc(c, &c->rnd_i, (size_t)8 * batch + 6 + 2 * IDAHIP_K_COUNT);
+    if (!c->rnd_d) rc |= dalloc(c, &c->rnd_d, (size_t)4 * batch);
+    if (rc) return rc;
+    if (!c->rnd_host) IDAHIP_HIP(c, hipHostMalloc((void**)&c->rnd_host, 4 * sizeof(int32_t)));
     const size_t ysz = (size_t)call->ntout * batch * n;
     IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_sys, hSys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyHostToDevice, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_touts, call->touts, sizeof(double) * call->ntout, hipMemcpyHostToDevice, c->stream));
@@ -1180,6 +1203,11 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
 }
 
 int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
+
+// LSolver::get_type / num_iters / res_norm of the dense direct solver (crates/linear/src/dense.rs:30-36, traits.rs:82-90)
+int idahip_ls_type(const idahip_ctx* c) { return c ? IDAHIP_LS_DIRECT : -1; }
+int idahip_ls_num_iters(const idahip_ctx* c) { return c ? 0 : -1; }
+double idahip_ls_res_norm(const idahip_ctx* c) { (void)c; return 0.0; }
 
 #ifdef IDAHIP_STAMPS
 /* timing builds: a device buffer for in-kernel time stamps (8 per workgroup of the instrumented launch) */

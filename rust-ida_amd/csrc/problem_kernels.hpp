@@ -332,4 +332,12 @@ __global__ __launch_bounds__(256) void callback_pack_kernel(const double* __rest
     }
 }
 
+// the user's Jacobians of a chunk of listed systems (staged contiguously, column-major) into their work matrices
+__global__ __launch_bounds__(256) void callback_scatter_jac_kernel(const double* __restrict__ stage, double* __restrict__ work,
+                                                                   const int* __restrict__ idx, long nn) {
+    const double* __restrict__ src = stage + (long)blockIdx.x * nn;
+    double* __restrict__ dst = work + (long)idx[blockIdx.x] * nn;
+    for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < nn; e += (long)gridDim.y * 256) dst[e] = src[e];
+}
+
 }  // namespace idahip

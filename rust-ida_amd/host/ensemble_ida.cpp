@@ -71,6 +71,7 @@ struct idaens {
     double t0 = 0.0;                // every system starts at tn = t0 (Sys default)
     int64_t retired_iters = 0, passes = 0;  // idaens_stream: Newton iterations / integrations of systems already restarted
     bool have_ic = false, streaming = false;
+    bool pow_mismatch = false; // glibc_pow.hpp != this host's std::pow (checked at create): the device steppers stay off
     bool device_ctl = true;    // small device problems: the whole of Ida::solve in one launch (idahip_tiny_solve), no lock-step rounds
     bool fused_newton = true;  // first two Newton iterations and their convergence tests in one device call (idahip_newton_iter2)
     std::vector<int64_t> start_round;  // idaens_stream with a stagger: the round at which each system first enters
@@ -450,7 +451,13 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
         }
         if (I.empty()) break;
         sc.clear();
-        for (int b : I) sc.push_back(S[b].cjratio != 1.0 ? 2.0 / (1.0 + S[b].cjratio) : 1.0);  // ida_ls.rs:406-410
+        {   // idaLsSolve's bookkeeping around LSolver::solve (ida_ls.rs:316-418): the solver's type decides the tolerance it is
+            // given (0 for a direct solver: idahip_ls_solve ignores it), the nli / ncfl counters and whether the correction is
+            // scaled by 2 / (1 + cjratio) (:405-410). The library's solver is Direct with no iterations and no failures.
+            const int lst = idahip_ls_type(e->ctx);
+            const long nli_inc = idahip_ls_num_iters(e->ctx);
+            for (int b : I) sc.push_back(after_lsolve(S[b], lst, nli_inc, false) ? 2.0 / (1.0 + S[b].cjratio) : 1.0);
+        }
         C.clear();
         // what follows a convergence test (newton.rs:109-153): converged / iterate again / ConvergenceRecover
         auto after_ctest = [&](int b, int ret, bool converged) {
@@ -738,6 +745,37 @@ int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const doubl
         return rc;
     }
     e->have_ic = idahip_snapshot_initial(ctx) == 0;  // for idaens_stream's restarts; costs two batch-sized vectors
+    // The device steppers decide step sizes and orders with glibc_pow.hpp, a restatement of ONE libm's pow; the host stepper
+    // (and the reference's f64::powf) use this host's std::pow. The two agree bit for bit on the hosts this was built for
+    // (tests/test_glibc_pow.py); on another libm they need not, and the two steppers would then take different step
+    // sequences without a sign. Checked once per process on the controller's argument ranges: on a mismatch the ensemble
+    // stays on the host stepper and says so in its error text.
+    static int g_pow_ok = -1;
+    if (g_pow_ok < 0) {
+        std::vector<double> x, y, r;
+        unsigned long long z = 0x9E3779B97F4A7C15ull;
+        auto u01 = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (double)(z >> 11) / 9007199254740992.0; };
+        for (int i = 0; i < 384; ++i) {
+            const int k = 1 + i % 6;
+            x.push_back(1.0e-4 + 3.0 * u01());                      // 2 err + 0.0001 (handle_n_flag, complete_step), delnrm / oldnrm (ctest)
+            y.push_back((i & 1) ? -1.0 / (double)(k + 1) : 1.0 / (double)k);
+        }
+        r.resize(x.size());
+        g_pow_ok = 1;
+        if (idahip_pow_batch(ctx, x.data(), y.data(), r.data(), x.size()) != 0) {
+            g_pow_ok = 0;
+        } else {
+            for (size_t i = 0; i < x.size(); ++i) {
+                const double h = std::pow(x[i], y[i]);
+                if (std::memcmp(&h, &r[i], sizeof h) != 0) g_pow_ok = 0;
+            }
+        }
+    }
+    if (!g_pow_ok) {
+        e->device_ctl = false;
+        e->pow_mismatch = true;
+        e->err = "the device pow does not reproduce this host's std::pow bit for bit: the device steppers are off (host stepper in use)";
+    }
     *out = e;
     return 0;
 }
@@ -761,8 +799,8 @@ int idaens_set_max_num_steps(idaens* e, long mxstep) {
 }
 int idaens_set_device_controller(idaens* e, int on) {
     if (!e) return -1;
-    e->device_ctl = on != 0;
-    return 0;
+    e->device_ctl = on != 0 && !e->pow_mismatch;
+    return (on != 0 && e->pow_mismatch) ? 1 : 0;  // 1: refused (see idaens_last_error)
 }
 int idaens_set_fused_newton(idaens* e, int on) {
     if (!e) return -1;
@@ -1255,6 +1293,8 @@ int idaens_get_counter(const idaens* e, int which, int64_t* out) {
             case IDAENS_C_NLUFAIL: v = s.nlufail; break;
             case IDAENS_C_NCONV_JCUR: v = s.nconv_jcur; break;
             case IDAENS_C_NFAIL_FIRST: v = s.nfail_first; break;
+            case IDAENS_C_NLI: v = s.nli; break;
+            case IDAENS_C_NCFL: v = s.ncfl; break;
             default: return -2;
         }
         out[b] = v;

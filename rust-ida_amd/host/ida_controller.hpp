@@ -67,6 +67,7 @@ struct SysCore {
     // --- IdaNLProblem / IdaLProblem scalars (src/ida_nls.rs:27-59, src/ida_ls.rs:84-105)
     double cj = 0.0, cjold = 0.0, cjratio = 0.0, ss = 0.0, oldnrm = 0.0, toldel = 0.0;
     long nre = 0, nsetups = 0, nje = 0;
+    long nli = 0, ncfl = 0;  // idaLsSolve's counters (ida_ls.rs:389-418): linear iterations, linear convergence failures
     // --- Newton (crates/nonlinear/src/newton.rs:14-32)
     bool jcur = false;
     int curiter = 0;
@@ -181,6 +182,18 @@ IDA_HD inline void after_lsetup(SysCore& s, int info) {
     s.cjratio = 1.0;
     s.ss = 20.0;
     s.nls_ret = info ? NLS_LSETUP_RECVR : NLS_SUCCESS;
+}
+
+// ---------------------------------------------------------------- idaLsSolve's bookkeeping around LSolver::solve (ida_ls.rs:316-418)
+// ls_type: LSolverType (0 Direct, 1 Iterative, 2 MatrixIterative; include/ida_hip.h). Returns the tolerance the solver is to be
+// called with: sqrt(N) * eplifac for an iterative solver, 0 for a direct one (:323-329).
+IDA_HD inline double lsolve_tol(int ls_type, double sqrt_n, double eplifac) { return ls_type == 0 ? 0.0 : sqrt_n * eplifac; }
+// after the solve: nli += num_iters for an iterative solver (:389-400), ncfl += 1 when the solver failed (:413-415); returns
+// whether the correction is to be scaled by 2 / (1 + cjratio) -- direct and matrix-iterative solvers only (:405-410)
+IDA_HD inline bool after_lsolve(SysCore& s, int ls_type, long num_iters, bool failed) {
+    if (ls_type != 0) s.nli += num_iters;
+    if (failed) s.ncfl += 1;
+    return (ls_type == 0 || ls_type == 2) && s.cjratio != 1.0;
 }
 
 // ---------------------------------------------------------------- idaNlsConvTest (ida_nls.rs:218-266) for iteration m = s.curiter

@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots", "idaens_set_root_fn",
@@ -94,6 +94,10 @@ def load():
     H.idahip_ls_setup.argtypes = [vp, vp, vp, i32p, i32p, ci]
     H.idahip_ls_solve.argtypes = [vp, vp, vp, vp, vp, cd, i32p, ci]
     H.idahip_wrms.argtypes = [vp, vp, vp, dp, i32p, ci]
+    H.idahip_ls_type.argtypes = [vp]
+    H.idahip_ls_num_iters.argtypes = [vp]
+    H.idahip_ls_res_norm.argtypes = [vp]
+    H.idahip_ls_res_norm.restype = cd
     H.idahip_nls_sys.argtypes = [vp, dp, dp, ci, i32p, ci]
     H.idahip_nls_lsetup.argtypes = [vp, dp, dp, i32p, i32p, ci]
     H.idahip_nls_sys_setup.argtypes = [vp, dp, dp, ci, i32p, i32p, ci]
@@ -187,6 +191,12 @@ class Ctx:
         if cause is not None:
             raise IdaHipError(message + " [Python callback raised %s: %s]" % (type(cause).__name__, cause)) from cause
         raise IdaHipError(message)
+
+    def take_callback_error(self):
+        """The exception a Python callback (residual, Jacobian or root function) raised since the last call of this method,
+        or None; the stored exception is cleared, so that it is not attached to a later, unrelated error."""
+        err, self._cb_error = getattr(self, "_cb_error", None), None
+        return err
 
     def all_idx(self):
         return np.arange(self.batch, dtype=np.int32)
@@ -397,7 +407,7 @@ class Ctx:
 
 
 COUNTERS = {"nst": 0, "nre": 1, "nje": 2, "nsetups": 3, "nni": 4, "netf": 5, "ncfn": 6, "n_attempts": 7, "nls_nconvfails": 8,
-            "kused": 9, "kk": 10, "nge": 11, "nlufail": 12, "nconv_jcur": 13, "nfail_first": 14}
+            "kused": 9, "kk": 10, "nge": 11, "nlufail": 12, "nconv_jcur": 13, "nfail_first": 14, "nli": 15, "ncfl": 16}
 REALS = {"tn": 0, "hused": 1, "hh": 2, "h0u": 3, "tolsf": 4}
 
 
@@ -439,7 +449,8 @@ class Ensemble:
 
     def set_root_fn(self, nroots, fn):
         """Root::root for any function: fn(sys, t, yy, yp) -> nroots values g_i (yy, yp: numpy views valid during the call).
-        An exception inside fn fails that system with IDAENS_RTFUNC_FAIL (-12) and is kept on the Ctx (`last_callback_error`)."""
+        An exception inside fn fails that system with IDAENS_RTFUNC_FAIL (-12); it is kept on the Ctx and handed out -- once --
+        by `Ctx.take_callback_error()` (solve / solve_schedule do not raise for a per-system status)."""
         ens = self
 
         def thunk(user, sys, t, yy, yp, nr, gout):

@@ -364,7 +364,8 @@ def test_user_root_function_through_the_host_callback():
     ens.set_root_fn(1, bad)
     st, tret = ens.solve(0.2)
     assert st[4] == -12 and (np.delete(st, 4) == 0).all()
-    assert isinstance(ens.ctx._cb_error, ValueError)
+    assert isinstance(ens.ctx.take_callback_error(), ValueError)
+    assert ens.ctx.take_callback_error() is None  # handed out once: not attached to a later, unrelated error
     ens.close()
 
 
