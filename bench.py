@@ -163,8 +163,8 @@ class Runner:
         96 rounds of round 1, +-2 % with the calibrated 62 (tools/round_profile.py)."""
         import idahip
         from idahip import problems
-        ns = min(nsample, prob["yy0"].shape[0])
-        sub = {k: (v[:ns] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == prob["yy0"].shape[0] else v) for k, v in prob.items()}
+        ns = min(nsample, prob["yy0"].shape[0], prob.get("matrices_on_host", 1 << 30))
+        sub = {k: (v[:ns] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] >= ns and k not in ("atol", "touts") else v) for k, v in prob.items()}
         ctx = problems.make_ctx(sub, device=device)
         ens = idahip.Ensemble(ctx, sub["yy0"], sub["yp0"])
         status, _, reached = ens.solve_schedule(sub["touts"])
@@ -174,12 +174,12 @@ class Runner:
         ctx.close()
         return max(1, int(round(float(np.median(att)))))
 
-    def __init__(self, prob, device):
+    def __init__(self, prob, device, ctx=None):
         import idahip
         from idahip import problems
         self.prob = prob
         self.stagger = self.STAGGER if self.STAGGER is not None else self.integration_length(prob, device, self.CALIBRATION_SYSTEMS)
-        self.ctx = problems.make_ctx(prob, device=device)
+        self.ctx = ctx if ctx is not None else problems.make_ctx(prob, device=device)
         self.ens = idahip.Ensemble(self.ctx, prob["yy0"], prob["yp0"])
         if TIME_ALL:
             self.ctx.timing(2)
@@ -258,6 +258,49 @@ def cpu_baseline(prob_small, cores):
                          iters, seconds)}
 
 
+def inputs_only(args, rank, world, first, count, procs):
+    """`--inputs-only`: what an N-rank start costs the HOST before the first barrier -- every rank generates its shard exactly as
+    the bench does (slice by slice; the upload is left out), rank 0 collects every rank's record and prints one JSON line. No GPU, no torch."""
+    import resource
+    from idahip import problems
+    t0 = time.time()
+    nsl, checksum = 0, 0.0
+    if args.workload == "linear_dense":
+        for s0, A, Bm, cs, ys, yps in problems.linear_dense_slices(args.n, count, first, procs):
+            nsl += 1
+            checksum += float(A[0, 0, 0]) + float(Bm[-1, -1, -1])
+            del A, Bm, cs, ys, yps
+    t_gen = time.time() - t0
+    rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0  # GiB (ru_maxrss is in KiB)
+    rec = (rank, round(t_gen, 2), round(rss, 2), nsl)
+    allr = [rec]
+    if world > 1:
+        # The ranks meet through files, not through torch.distributed: importing torch opens the GPU, and this mode must be
+        # able to run eight ranks on a one-GPU box (at most six processes may hold the card there). The gloo meeting itself is
+        # what tests/test_sharding_gloo.py and the 2- and 4-rank rehearsals of tests/test_gpu_bench_ranks.py cover.
+        import tempfile
+        d = os.path.join(tempfile.gettempdir(), "idahip_inputs_only_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.makedirs(d, exist_ok=True)
+        tmp = os.path.join(d, "rank%d.tmp" % rank)
+        with open(tmp, "w") as f:
+            json.dump(rec, f)
+        os.replace(tmp, os.path.join(d, "rank%d.json" % rank))
+        if rank == 0:
+            deadline = time.time() + 1800
+            while time.time() < deadline and not all(os.path.exists(os.path.join(d, "rank%d.json" % r)) for r in range(world)):
+                time.sleep(0.05)
+            allr = [tuple(json.load(open(os.path.join(d, "rank%d.json" % r)))) for r in range(world)]
+            for r in range(world):
+                os.remove(os.path.join(d, "rank%d.json" % r))
+            os.rmdir(d)
+    if rank == 0:
+        print(json.dumps({"inputs_only": True, "workload": args.workload, "n": args.n, "batch_per_rank": args.batch, "ranks": world,
+                          "generator_processes_per_rank": procs, "seconds_until_every_rank_has_its_inputs_max": max(r[1] for r in allr),
+                          "peak_rss_GiB_per_rank": [r[2] for r in allr], "slices_per_rank": allr[0][3],
+                          "seconds_per_rank": [r[1] for r in allr]}))
+    sys.exit(0)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
     loaded torch or touched HIP) and leave with the worst of their exit codes. Rank 0 prints the JSON line."""
@@ -299,6 +342,9 @@ def main():
                     help="linear_dense = config 3 (the headline, N=512 B=4096); heat1d = config 4 (N=4096 B=256); lorenz63 = config 2 (N=3 B=1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-pass figures (N = 1 extras)")
+    ap.add_argument("--inputs-only", action="store_true",
+                    help="host-side rehearsal of an N-rank start: every rank generates its shard (slice by slice, as for the upload), "
+                         "rank 0 collects and prints seconds and peak resident memory per rank; no GPU is touched (torch is not imported)")
     args = ap.parse_args()
     dn, db = {"linear_dense": (512, 4096), "heat1d": (4096, 256), "lorenz63": (3, 1024)}[args.workload]
     args.n = dn if args.n is None else args.n
@@ -317,8 +363,18 @@ def main():
     procs = int(os.environ.get("IDAHIP_GEN_PROCS", max(1, min(16, cores // max(1, world)))))  # 1 = in-process (use under rocprofv3)
     t0 = time.time()
     first, count = sharding.shard_range(rank, world, args.batch)
+    stream_ctx = None
+    ncpu = max(1, min(cores, 64))
+    nsmall = min(args.batch, 16 * ncpu if args.workload == "linear_dense" else (ncpu if args.workload == "heat1d" else args.batch))
+    if args.inputs_only:
+        inputs_only(args, rank, world, first, count, procs)  # does not return
     if args.workload == "linear_dense":
-        prob = problems.linear_dense(n=args.n, batch=count, first=first, procs=procs)
+        # the shard's matrices go from the generator to the device a slice (<= 2 GiB) at a time: the process never holds the
+        # 17 GB host copy of its shard (eight ranks of a node would hold 137 GB), only the calibration / CPU-baseline sample
+        keep = max(Runner.CALIBRATION_SYSTEMS, nsmall if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
+        rehearse_early = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
+        stream_ctx, prob = problems.make_ctx_linear_dense_streamed(args.n, count, first=first, procs=procs,
+                                                                  device=0 if rehearse_early else local_rank, keep=keep)
     else:
         full = problems.heat1d(n=args.n, batch=args.batch * world) if args.workload == "heat1d" else problems.lorenz63(batch=args.batch * world)
         prob = {k: (v[first:first + count] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
@@ -327,9 +383,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ncpu = max(1, min(cores, 64))
-        nsmall = min(args.batch, 16 * ncpu if args.workload == "linear_dense" else (ncpu if args.workload == "heat1d" else args.batch))
-        small = {k: (v[:nsmall] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == args.batch else v) for k, v in prob.items()}
+        small = {k: (v[:nsmall] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] >= nsmall else v) for k, v in prob.items()}
         cpu = cpu_baseline(small, ncpu)
 
     import torch
@@ -357,7 +411,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(prob, local_rank)
+    run = Runner(prob, local_rank, ctx=stream_ctx)
     prob.pop("A", None)  # host copies no longer needed
     prob.pop("B", None)
 

@@ -158,6 +158,73 @@ def linear_dense(n=512, batch=4096, first=0, procs=1, nthreads=1):
             "atol": np.array([1.0e-8]), "touts": 0.1 * np.arange(1, 11)}
 
 
+def linear_dense_slices(n=512, batch=4096, first=0, procs=1, slice_bytes=1 << 31):
+    """Config 3/5 generated a slice at a time: yields (s0, A, B, c, yy0, yp0) for consecutive slices of at most `slice_bytes`
+    of matrices (A and B together), systems [first + s0, first + s0 + len) -- the same systems, bit for bit, as linear_dense.
+    The consumer (bench.py: upload to the device) sees one slice at a time, so a process never holds more than a slice of its
+    shard on the host: eight ranks of a node then need 8 x ~4 GB instead of 8 x 17 GB. The arrays of a slice are only valid
+    until the next one is requested."""
+    per = max(1, slice_bytes // max(1, 16 * n * n))
+    if procs > 1 and batch >= 2 * procs:
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        per = max(2 * procs, min(batch, per))
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["numpy"])
+        with ctx.Pool(procs) as pool:
+            for s0 in range(0, batch, per):
+                cnt = min(per, batch - s0)
+                shapes = [(cnt, n, n), (cnt, n, n), (cnt, n), (cnt, n), (cnt, n)]
+                blocks = [shared_memory.SharedMemory(create=True, size=max(8, int(np.prod(sh)) * 8)) for sh in shapes]
+                try:
+                    step = max(1, cnt // (procs * 4))
+                    names = [b.name for b in blocks]
+                    jobs = [(n, first + s0, lo, min(cnt, lo + step), True, names, shapes) for lo in range(0, cnt, step)]
+                    assert sum(pool.map(_fill_range, jobs)) == cnt
+                    views = [np.ndarray(sh, dtype=np.float64, buffer=b.buf) for sh, b in zip(shapes, blocks)]
+                    yield (s0,) + tuple(views)
+                    del views
+                finally:
+                    for b in blocks:
+                        b.close()
+                        b.unlink()
+    else:
+        for s0 in range(0, batch, per):
+            cnt = min(per, batch - s0)
+            shapes = [(cnt, n, n), (cnt, n, n), (cnt, n), (cnt, n), (cnt, n)]
+            arrays = [np.empty(sh) for sh in shapes]
+            _SHARED["arrays"] = arrays
+            _fill_range((n, first + s0, 0, cnt, False, None, shapes))
+            _SHARED.pop("arrays")
+            yield (s0,) + tuple(arrays)
+
+
+def make_ctx_linear_dense_streamed(n, batch, first=0, procs=1, device=0, stream=None, keep=0, slice_bytes=1 << 31):
+    """Device context of `batch` config-3 systems [first, first + batch) whose matrices go from the generator to the device a
+    slice at a time (linear_dense_slices). Returns (ctx, prob): prob has everything linear_dense returns except that "A" and
+    "B" only hold the first `keep` systems (the calibration sample / the CPU baseline's sample)."""
+    from . import Ctx
+    ctx = Ctx("linear_dense", n, batch, device=device, stream=stream)
+    rtol, atol = 1.0e-6, np.array([1.0e-8])
+    ctx.set_tolerances(rtol, atol)
+    c, y0, yp0 = np.empty((batch, n)), np.empty((batch, n)), np.empty((batch, n))
+    keep = min(keep, batch)
+    Ak, Bk = np.empty((keep, n, n)), np.empty((keep, n, n))
+    up = max(1, (1 << 28) // (8 * n * n))  # <= 256 MiB per matrix upload
+    for s0, A, Bm, cs, ys, yps in linear_dense_slices(n, batch, first, procs, slice_bytes):
+        cnt = A.shape[0]
+        for f in range(0, cnt, up):
+            ctx.set_linear_dense(A[f:f + up], Bm[f:f + up], cs[f:f + up], first=s0 + f)
+        c[s0:s0 + cnt], y0[s0:s0 + cnt], yp0[s0:s0 + cnt] = cs, ys, yps
+        if s0 < keep:
+            m = min(cnt, keep - s0)
+            Ak[s0:s0 + m], Bk[s0:s0 + m] = A[:m], Bm[:m]
+        del A, Bm, cs, ys, yps
+    prob = {"kind": "linear_dense", "n": n, "A": Ak, "B": Bk, "c": c, "yy0": y0, "yp0": yp0, "rtol": rtol, "atol": atol,
+            "touts": 0.1 * np.arange(1, 11), "matrices_on_host": keep}
+    return ctx, prob
+
+
 def heat1d(n=4096, batch=256):
     """Config 4 -- 1-D heat equation u_t = kappa u_xx, method of lines on n nodes, Dirichlet ends as algebraic equations;
     kappa_b = 1 + b/256; y_i(0) = sin(pi x_i) with exact zeros at both ends; y'(0) = the interior right-hand side."""

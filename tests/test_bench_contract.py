@@ -64,3 +64,19 @@ def test_self_launch_prepares_one_fresh_process_per_rank(monkeypatch):
     for r, (cmd, env) in enumerate(started):
         assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "3" and env["MASTER_ADDR"] == "127.0.0.1"
         assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "3", "--steps", "5"]
+
+
+def test_eight_rank_start_rehearsed_on_the_host_side():
+    """What `bench.py --gpus 8` needs from the HOST before its first barrier, at world size 8 (the driver's largest case) and a
+    small N: eight fresh rank processes, each generating its own shard slice by slice as for the upload, handing its record to rank 0
+    (through files: torch, which would open a GPU, is not imported); rank 0 reports seconds and peak resident memory per rank. No GPU is touched (`--inputs-only`), so this runs in the build
+    container; the full-size figures measured on a GPU box's host are in DESIGN.md section 6."""
+    import json
+    import subprocess
+    env = dict(os.environ, IDAHIP_GEN_PROCS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--inputs-only", "--n", "32", "--batch", "64"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["inputs_only"] and line["ranks"] == 8 and len(line["peak_rss_GiB_per_rank"]) == 8 and len(line["seconds_per_rank"]) == 8
+    assert line["slices_per_rank"] >= 1 and line["seconds_until_every_rank_has_its_inputs_max"] >= 0.0
