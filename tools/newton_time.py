@@ -5,7 +5,7 @@ import numpy as np, idahip
 from idahip import problems
 
 def main():
-    n, B = 512, 2048
+    n, B = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     p = problems.linear_dense(n=n, batch=B, procs=16)
     ctx = problems.make_ctx(p)
     ctx.upload(idahip.F_YY, p["yy0"]); ctx.upload(idahip.F_YP, p["yp0"])
