@@ -193,6 +193,14 @@ int idahip_restore_initial(idahip_ctx* ctx, const int32_t* hIdx, int nsys);
  *   hYout/hYPout optional raw dumps [ntout][batch][n] of the device-side output slots (a slot is written when its tout is
  *              reached; the caller knows from the states which slots are new)
  * idahip_pow_batch: the controller's pow for n argument pairs, computed on the device (test hook for glibc_pow.hpp). */
+/* Root finding on the device (src/impl_r_check.rs:32-576) for the function family of the reference's own example,
+ * g_i(t, y, y') = y[comp[i]] - threshold[i] (examples/roberts.rs:53-56): per-system state of `Ida`'s root fields
+ * (ida_glo, ida_ghi, ida_grout, ida_iroots, ida_gactive: src/lib.rs:225-244), moved with the controller record. */
+#define IDAHIP_MAX_ROOTS 4
+typedef struct idahip_root_state {
+    double glo[IDAHIP_MAX_ROOTS], ghi[IDAHIP_MAX_ROOTS], grout[IDAHIP_MAX_ROOTS], iroots[IDAHIP_MAX_ROOTS];
+    int32_t gactive[IDAHIP_MAX_ROOTS];
+} idahip_root_state;
 typedef struct idahip_tiny_call {
     const double* touts; /* [ntout] host */
     int ntout;
@@ -205,6 +213,10 @@ typedef struct idahip_tiny_call {
     double epcon, hmax_inv, t0;
     const int64_t* start_round; /* [batch] host or NULL: idaens_stream's staggered start (absolute round numbers) */
     int64_t round_base;         /* rounds executed before this call */
+    int nroots;                 /* 0, or the number of root functions (<= IDAHIP_MAX_ROOTS) */
+    const int32_t* root_comps;  /* [nroots] host */
+    const double* root_thresholds; /* [nroots] host */
+    idahip_root_state* root_states; /* [batch] host, in and out (NULL iff nroots == 0) */
 } idahip_tiny_call;
 int idahip_tiny_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
                       double* hYout, double* hYPout);

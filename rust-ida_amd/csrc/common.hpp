@@ -72,6 +72,7 @@ struct idahip_ctx {
     double *tiny_touts = nullptr, *tiny_yout = nullptr, *tiny_ypout = nullptr;
     int64_t *tiny_start = nullptr, *tiny_rounds = nullptr;
     uint64_t* tiny_acc = nullptr;
+    void* tiny_roots = nullptr;  // [batch] idahip_root_state (lazy: root finding on the device steppers)
     int tiny_ntout_cap = 0, tiny_yout_cap = 0;
 
     // device-resident lock-step stepper (round_ida.hpp): per-system round state, the LU list, the round summary (lazy)

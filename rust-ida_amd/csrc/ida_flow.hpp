@@ -27,15 +27,214 @@ struct FlowArgs {
     const long long* start_round;  // [batch] or null: idaens_stream's staggered start (absolute round numbers)
     unsigned long long* acc;       // [2] retired Newton iterations, completed passes (idaens_stream)
     int batch;
+    // root functions g_i = y[rt_comp[i]] - rt_thr[i] (nrt == 0: no root finding); their per-system state travels with the caller
+    int nrt = 0;
+    int rt_comp[IDAHIP_MAX_ROOTS] = {0};
+    double rt_thr[IDAHIP_MAX_ROOTS] = {0};
 };
 
 // V provides: init_first(&ypnorm, &p0nrm), scale_phi1(f), predict(s), post_newton(s, norms[4]), restore_vec(s, kk_att, ns_att),
-// complete_step_vec(s, kused, ck, maxord), get_solution_vec(s, kord), emit_output(slot), restore_initial()
+// complete_step_vec(s, kused, ck, maxord), get_solution_vec(s, kord), emit_output(slot), restore_initial(), and for the root
+// functions: sync() (the vector primitives' results are visible to every thread of the system), yy_at(i), phi_at(j, i),
+// yy_from_phi01(f) (yy = phi[0] + f * phi[1]), yy_add_phi1(f) (yy += f * phi[1])
 template <class V>
 struct IdaFlow {
     const FlowArgs& a;
     idactl::SysCore& s;
     V& v;
+    idahip_root_state* rt = nullptr;  // this system's root state (a.nrt > 0)
+
+    // ------------------------------------------------------------ root finding (src/impl_r_check.rs:32-576), as
+    // host/ensemble_ida.cpp runs it per system on the host -- here the bracketing is device code too: the interpolation of
+    // y(t) is the backend's get_solution_vec, the function family is evaluated in place, nothing crosses PCIe per evaluation.
+    __device__ void root_fn(double* g) const {  // g_i = y[comp_i] - thr_i at the current yy (examples/roberts.rs:53-56)
+        v.sync();
+        for (int i = 0; i < a.nrt; ++i) g[i] = v.yy_at(a.rt_comp[i]) - a.rt_thr[i];
+    }
+    // impl_r_check.rs:32-115 -- at the first call, before phi[1] is scaled by hh
+    __device__ void r_check1() const {
+        const double eps = 2.220446049250313e-16;
+        for (int i = 0; i < a.nrt; ++i) rt->iroots[i] = 0.0;
+        s.tlo = s.tn;
+        s.ttol = (fabs(s.tn) + fabs(s.hh)) * eps * 100.0;
+        for (int i = 0; i < a.nrt; ++i) rt->glo[i] = v.phi_at(0, a.rt_comp[i]) - a.rt_thr[i];  // g(tlo, phi[0], phi[1])
+        s.nge = 1;
+        bool zroot = false;
+        for (int i = 0; i < a.nrt; ++i)
+            if (fabs(rt->glo[i]) == 0.0) {
+                rt->gactive[i] = 0;
+                zroot = true;
+            }
+        if (zroot) {
+            const double hratio = fmax(s.ttol / fabs(s.hh), 0.1);
+            const double smallh = hratio * s.hh;
+            v.yy_from_phi01(smallh);  // yy = phi[0] + smallh * phi[1]
+            root_fn(rt->ghi);
+            s.nge += 1;
+            for (int i = 0; i < a.nrt; ++i)
+                if (!rt->gactive[i] && fabs(rt->ghi[i]) != 0.0) {
+                    rt->gactive[i] = 1;
+                    rt->glo[i] = rt->ghi[i];
+                }
+        }
+    }
+    // impl_r_check.rs:117-219 -- on re-entry after a root return. IDAENS_UNFINISHED (continue), ROOT_RETURN or < 0.
+    __device__ int r_check2() const {
+        const double eps = 2.220446049250313e-16;
+        if (!s.irfnd) return IDAENS_UNFINISHED;
+        int rc = get_solution(s.tlo);
+        if (rc) return rc;
+        root_fn(rt->glo);
+        s.nge += 1;
+        for (int i = 0; i < a.nrt; ++i) rt->iroots[i] = 0.0;
+        bool zroot = false;
+        for (int i = 0; i < a.nrt; ++i)
+            if (rt->gactive[i] && fabs(rt->glo[i]) == 0.0) {
+                zroot = true;
+                rt->iroots[i] = 1.0;
+            }
+        if (zroot) {
+            s.ttol = (fabs(s.tn) + fabs(s.hh)) * eps * 100.0;
+            const double smallh = s.ttol * idactl::signum(s.hh);
+            const double tplus = s.tlo + smallh;
+            if ((tplus - s.tn) * s.hh >= 0.0) {
+                const double hratio = smallh / s.hh;
+                v.sync();
+                v.yy_add_phi1(hratio);  // yy += hratio * phi[1]
+            } else {
+                rc = get_solution(tplus);
+                if (rc) return rc;
+            }
+            root_fn(rt->ghi);
+            s.nge += 1;
+            bool zroot2 = false;
+            for (int i = 0; i < a.nrt; ++i) {
+                if (!rt->gactive[i]) continue;
+                if (fabs(rt->ghi[i]) == 0.0) {
+                    if (rt->iroots[i] > 0.0) return IDAENS_CLOSE_ROOTS;
+                    zroot2 = true;
+                    rt->iroots[i] = 1.0;
+                } else if (rt->iroots[i] > 0.0) {
+                    rt->glo[i] = rt->ghi[i];
+                }
+            }
+            if (zroot2) return IDAENS_ROOT_RETURN;
+        }
+        return IDAENS_UNFINISHED;
+    }
+    __device__ void scan_roots(const double* gval, bool first, bool* zroot, bool* sgnchg, int* imax) const {
+        double maxfrac = 0.0;
+        *zroot = false;
+        *sgnchg = false;
+        for (int i = 0; i < a.nrt; ++i) {
+            if (!rt->gactive[i]) continue;
+            const bool rootdir_glo_neg = 0.0 * rt->glo[i] <= 0.0;  // rootdir is 0 (no setter in the reference, lib.rs:372)
+            if (first) {  // impl_r_check.rs:361-383
+                if (fabs(gval[i]) == 0.0) {
+                    if (rootdir_glo_neg) *zroot = true;
+                    continue;
+                }
+            } else if (fabs(gval[i]) == 0.0 && rootdir_glo_neg) {  // impl_r_check.rs:486-504
+                *zroot = true;
+                continue;
+            }
+            if (rt->glo[i] * gval[i] < 0.0 && rootdir_glo_neg) {
+                const double gfrac = fabs(gval[i] / (gval[i] - rt->glo[i]));
+                if (gfrac > maxfrac) {
+                    *sgnchg = true;
+                    maxfrac = gfrac;
+                    *imax = i;
+                }
+            }
+        }
+    }
+    // impl_r_check.rs:343-576 (modified secant / Illinois). IDAENS_UNFINISHED (no root), ROOT_RETURN or < 0.
+    __device__ int root_find() const {
+        const int nr = a.nrt;
+        int imax = 0;
+        bool zroot, sgnchg;
+        scan_roots(rt->ghi, true, &zroot, &sgnchg, &imax);
+        if (!sgnchg) {
+            s.trout = s.thi;
+            for (int i = 0; i < nr; ++i) rt->grout[i] = rt->ghi[i];
+            if (!zroot) return IDAENS_UNFINISHED;
+            for (int i = 0; i < nr; ++i) {
+                rt->iroots[i] = 0.0;
+                if (rt->gactive[i] && fabs(rt->ghi[i]) == 0.0 && 0.0 * rt->glo[i] <= 0.0) rt->iroots[i] = idactl::signum(rt->glo[i]);
+            }
+            return IDAENS_ROOT_RETURN;
+        }
+        double alph = 1.0;
+        int side = 0, sideprev = -1;
+        for (;;) {
+            if (fabs(s.thi - s.tlo) <= s.ttol) break;
+            if (sideprev == side) alph = (side == 2) ? alph * 2.0 : alph * 0.5;
+            else alph = 1.0;
+            double tmid = s.thi - (s.thi - s.tlo) * rt->ghi[imax] / (rt->ghi[imax] - alph * rt->glo[imax]);
+            if (fabs(tmid - s.tlo) < 0.5 * s.ttol) {
+                const double fracint = fabs(s.thi - s.tlo) / s.ttol;
+                const double fracsub = (fracint > 5.0) ? 0.1 : 0.5 / fracint;
+                tmid = s.tlo + fracsub * (s.thi - s.tlo);
+            }
+            if (fabs(s.thi - tmid) < 0.5 * s.ttol) {
+                const double fracint = fabs(s.thi - s.tlo) / s.ttol;
+                const double fracsub = (fracint > 5.0) ? 0.1 : 0.5 / fracint;
+                tmid = s.thi - fracsub * (s.thi - s.tlo);
+            }
+            const int rc = get_solution(tmid);
+            if (rc) return rc;
+            root_fn(rt->grout);
+            s.nge += 1;
+            sideprev = side;
+            scan_roots(rt->grout, false, &zroot, &sgnchg, &imax);
+            if (sgnchg) {
+                s.thi = tmid;
+                for (int i = 0; i < nr; ++i) rt->ghi[i] = rt->grout[i];
+                side = 1;
+                if (fabs(s.thi - s.tlo) <= s.ttol) break;
+                continue;
+            }
+            if (zroot) {
+                s.thi = tmid;
+                for (int i = 0; i < nr; ++i) rt->ghi[i] = rt->grout[i];
+                break;
+            }
+            s.tlo = tmid;
+            for (int i = 0; i < nr; ++i) rt->glo[i] = rt->grout[i];
+            side = 2;
+            if (fabs(s.thi - s.tlo) <= s.ttol) break;
+        }
+        s.trout = s.thi;
+        for (int i = 0; i < nr; ++i) rt->grout[i] = rt->ghi[i];
+        for (int i = 0; i < nr; ++i) {
+            rt->iroots[i] = 0.0;
+            if (rt->gactive[i] && 0.0 * rt->glo[i] <= 0.0 && (fabs(rt->ghi[i]) == 0.0 || rt->glo[i] * rt->ghi[i] < 0.0))
+                rt->iroots[i] = idactl::signum(rt->glo[i]);
+        }
+        return IDAENS_ROOT_RETURN;
+    }
+    // impl_r_check.rs:221-280 -- after a successful step. IDAENS_UNFINISHED (no root), ROOT_RETURN or < 0.
+    __device__ int r_check3() const {
+        const double eps = 2.220446049250313e-16;
+        if (s.taskc == IDAENS_ONE_STEP) s.thi = s.tn;
+        else s.thi = ((s.toutc - s.tn) * s.hh >= 0.0) ? s.tn : s.toutc;
+        int rc = get_solution(s.thi);
+        if (rc) return rc;
+        root_fn(rt->ghi);
+        s.nge += 1;
+        s.ttol = (fabs(s.tn) + fabs(s.hh)) * eps * 100.0;
+        const int ier = root_find();
+        if (ier < 0) return ier;
+        for (int i = 0; i < a.nrt; ++i)
+            if (!rt->gactive[i] && rt->grout[i] != 0.0) rt->gactive[i] = 1;
+        s.tlo = s.trout;
+        for (int i = 0; i < a.nrt; ++i) rt->glo[i] = rt->grout[i];
+        if (ier == IDAENS_ROOT_RETURN) {
+            rc = get_solution(s.trout);
+            if (rc) return rc;
+        }
+        return ier;
+    }
 
     // get_solution(t) into yy/yp; returns 0 or IDAENS_BAD_T
     __device__ int get_solution(double t) const {
@@ -70,11 +269,40 @@ struct IdaFlow {
         }
         return IDAENS_UNFINISHED;
     }
-    // entry of one Ida::solve(s.tout_cur) call (impl_solve.rs:179-241, no roots)
+    // entry of one Ida::solve(s.tout_cur) call (impl_solve.rs:179-241)
     __device__ int enter_call() const {
         s.nstloc = 0;
         s.toutc = s.tout_cur;
         s.taskc = IDAENS_NORMAL;
+        if (s.nst > 0 && a.nrt > 0) {  // impl_solve.rs:187-229
+            const double eps = 2.220446049250313e-16;
+            int ier = r_check2();
+            if (ier < 0) {
+                s.dead = true;
+                return ier;
+            }
+            if (ier == IDAENS_ROOT_RETURN) {
+                s.tretlast = s.tlo;
+                s.tret = s.tlo;
+                return IDAENS_ROOT_RETURN;
+            }
+            const double troundoff = (fabs(s.tn) + fabs(s.hh)) * eps * 100.0;
+            if (fabs(s.tn - s.tretlast) > troundoff) {
+                ier = r_check3();
+                if (ier < 0) {
+                    s.dead = true;
+                    return ier;
+                }
+                if (ier == IDAENS_UNFINISHED) {
+                    s.irfnd = false;
+                } else {  // root found
+                    s.irfnd = true;
+                    s.tretlast = s.tlo;
+                    s.tret = s.tlo;
+                    return IDAENS_ROOT_RETURN;
+                }
+            }
+        }
         if (s.nst > 0) {
             const int istate = stop_test1(s.tout_cur);
             if (istate != IDAENS_UNFINISHED) {
@@ -129,6 +357,8 @@ struct IdaFlow {
                 s.eps_newt = a.epcon;
                 s.toldel = 0.0001 * s.eps_newt;
                 s.phi0nrm = p0nrm;
+                if (a.nrt > 0) r_check1();  // impl_solve.rs:157-159
+                v.sync();
                 v.scale_phi1(s.hh);  // phi[1] = hh * y'
             }
         }
@@ -219,6 +449,23 @@ struct IdaFlow {
         v.complete_step_vec(s, s.kused, s.ck, a.maxord);
         s.nstloc += 1;
         s.ph = idactl::PH_LOOP_TOP;
+        if (a.nrt > 0) {  // impl_solve.rs:343-356
+            const int ier = r_check3();
+            if (ier < 0) {
+                s.status = ier;
+                s.dead = true;
+                s.ph = idactl::PH_IDLE;
+                return false;
+            }
+            if (ier == IDAENS_ROOT_RETURN) {
+                s.irfnd = true;
+                s.tretlast = s.tlo;
+                s.tret = s.tlo;
+                s.status = IDAENS_ROOT_RETURN;
+                s.ph = idactl::PH_IDLE;
+                return false;
+            }
+        }
         const int istate = stop_test2(s.tout_cur);
         if (istate != IDAENS_UNFINISHED) {
             s.status = istate;

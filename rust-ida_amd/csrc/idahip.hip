@@ -139,7 +139,7 @@ int idahip_destroy(idahip_ctx* c) {
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
                     c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
-                    c->tiny_acc, c->rnd_i, c->rnd_d};
+                    c->tiny_acc, c->tiny_roots, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->rnd_host) (void)hipHostFree(c->rnd_host);
@@ -989,6 +989,11 @@ static FlowArgs flow_args(idahip_ctx* c, const idahip_tiny_call* call) {
     f.start_round = call->start_round ? (const long long*)c->tiny_start : nullptr;
     f.acc = (unsigned long long*)c->tiny_acc;
     f.batch = c->batch;
+    f.nrt = call->nroots;
+    for (int i = 0; i < call->nroots && i < IDAHIP_MAX_ROOTS; ++i) {
+        f.rt_comp[i] = call->root_comps[i];
+        f.rt_thr[i] = call->root_thresholds[i];
+    }
     return f;
 }
 
@@ -1017,6 +1022,7 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     a.savres = c->savres; a.lu = c->lu; a.piv = (long long*)c->piv; a.params = c->params; a.nparam = c->nparam;
     a.ic_y = c->ic_y; a.ic_yp = c->ic_yp;
     a.f = flow_args(c, call);
+    a.roots = (idahip_root_state*)c->tiny_roots;
     a.max_rounds = call->max_rounds;
     a.round_base = call->round_base;
     a.yout = hYout ? c->tiny_yout : nullptr;
@@ -1037,6 +1043,8 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
         if ((rc = post_launch(c, "tiny_ida"))) return rc;
     }
     IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));
+    if (call->nroots > 0)
+        IDAHIP_HIP(c, hipMemcpyAsync(call->root_states, c->tiny_roots, (size_t)batch * sizeof(idahip_root_state), hipMemcpyDeviceToHost, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(hRoundsDone, c->tiny_rounds, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(hAcc, c->tiny_acc, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (hYout) IDAHIP_HIP(c, hipMemcpyAsync(hYout, c->tiny_yout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));
@@ -1056,6 +1064,15 @@ static int stepper_buffers(idahip_ctx* c, const idahip_tiny_call* call, bool out
     if (!c->tiny_rounds) rc |= dalloc(c, &c->tiny_rounds, (size_t)batch);
     if (!c->tiny_acc) rc |= dalloc(c, &c->tiny_acc, (size_t)2);
     if (rc) return rc;
+    if (call->nroots < 0 || call->nroots > IDAHIP_MAX_ROOTS) return fail(c, -2, "the device steppers take at most %d root functions", IDAHIP_MAX_ROOTS);
+    if (call->nroots > 0) {
+        if (!call->root_comps || !call->root_thresholds || !call->root_states) return fail(c, -2, "root functions without their arrays");
+        for (int i = 0; i < call->nroots; ++i)
+            if (call->root_comps[i] < 0 || call->root_comps[i] >= n) return fail(c, -2, "root function %d watches component %d of %d", i, call->root_comps[i], n);
+        if (call->recycle) return fail(c, -2, "root finding and idaens_stream's restarts do not combine");
+        if (!c->tiny_roots) IDAHIP_HIP(c, hipMalloc(&c->tiny_roots, (size_t)batch * sizeof(idahip_root_state)));
+        IDAHIP_HIP(c, hipMemcpyAsync(c->tiny_roots, call->root_states, (size_t)batch * sizeof(idahip_root_state), hipMemcpyHostToDevice, c->stream));
+    }
     if (call->ntout > c->tiny_ntout_cap) {
         if (c->tiny_touts) (void)hipFree(c->tiny_touts);
         c->tiny_touts = nullptr;
@@ -1110,6 +1127,7 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     a.ypout = hYPout ? c->tiny_ypout : nullptr;
     a.round_base = call->round_base;
     a.fused_jac = c->kind == IDAHIP_LINEAR_DENSE ? 1 : 0;
+    a.roots = (idahip_root_state*)c->tiny_roots;
     int* ib = c->rnd_i;
     a.stepping = ib; a.in_newton = ib + batch; a.skipP = ib + 2 * batch; a.skipL = ib + 3 * batch; a.skipI = ib + 4 * batch;
     a.skipS = ib + 5 * batch; a.ident = ib + 6 * batch; a.lu_list = ib + 7 * batch; a.lu_cnt = ib + 8 * batch; a.summary = ib + 8 * batch + 1;
@@ -1190,6 +1208,8 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     (void)shm_it;
     *rounds_run = r;
     IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));
+    if (call->nroots > 0)
+        IDAHIP_HIP(c, hipMemcpyAsync(call->root_states, c->tiny_roots, (size_t)batch * sizeof(idahip_root_state), hipMemcpyDeviceToHost, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(hRoundsDone, c->tiny_rounds, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, c->stream));
     IDAHIP_HIP(c, hipMemcpyAsync(hAcc, c->tiny_acc, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (hYout) IDAHIP_HIP(c, hipMemcpyAsync(hYout, c->tiny_yout, sizeof(double) * ysz, hipMemcpyDeviceToHost, c->stream));

@@ -50,6 +50,7 @@ struct RoundArgs {
     long long* rounds_done; // [batch]
     unsigned long long* stats;  // [IDAHIP_K_COUNT] systems served per kernel class in this call (the event timers' bookkeeping)
     int* summary;           // [2]: systems stepping after this round (zeroed before every round), systems that failed (this call)
+    idahip_root_state* roots;  // [batch] or null (f.nrt == 0)
 };
 
 // vector backend of IdaFlow: a workgroup of WG_NT threads (one wavefront: every lane runs the scalar logic, in lock-step, on the
@@ -182,6 +183,16 @@ struct WgVec {
             a.v.yp[vb + i] = yp;
         }
     }
+    // root functions (ida_flow.hpp): an element of yy may have been written by another thread of the workgroup
+    __device__ void sync() const { __syncthreads(); }
+    __device__ double yy_at(int i) const { return a.v.yy[vb + i]; }
+    __device__ double phi_at(int j, int i) const { return a.v.phi[j * a.v.phistride + vb + i]; }
+    __device__ void yy_from_phi01(double f) const {
+        for (int i = threadIdx.x; i < n; i += WG_NT) a.v.yy[vb + i] = phi(0, i) + f * phi(1, i);
+    }
+    __device__ void yy_add_phi1(double f) const {
+        for (int i = threadIdx.x; i < n; i += WG_NT) a.v.yy[vb + i] = a.v.yy[vb + i] + f * phi(1, i);
+    }
     __device__ void emit_output(int slot) const {
         // (yy / yp were written by this thread's own get_solution_vec just before, same index mapping: no barrier needed)
         if (a.yout)
@@ -212,15 +223,22 @@ __device__ __forceinline__ void wg_copy_words(void* dst, const void* src) {
         static_cast<unsigned long long*>(dst)[i] = static_cast<const unsigned long long*>(src)[i];
 }
 
+static_assert(sizeof(idahip_root_state) % 8 == 0 && sizeof(idahip_root_state) / 8 <= WG_NT, "word copies of the root state by one wave");
+__device__ __forceinline__ void wg_copy_root(void* dst, const void* src) {
+    if (threadIdx.x < (int)(sizeof(idahip_root_state) / 8)) static_cast<unsigned long long*>(dst)[threadIdx.x] = static_cast<const unsigned long long*>(src)[threadIdx.x];
+}
+
 __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
     __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
+    __shared__ __align__(16) idahip_root_state s_rt;
     wg_copy_words(s_raw, a.sys + b);
+    if (a.f.nrt > 0) wg_copy_root(&s_rt, a.roots + b);
     __syncthreads();
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
-    const IdaFlow<WgVec> F{a.f, s, v};
+    const IdaFlow<WgVec> F{a.f, s, v, a.f.nrt > 0 ? &s_rt : nullptr};
     const long long ground = a.round_base + a.round;
     bool stepping = a.first_round ? F.enter(ground, b) : (a.stepping[b] != 0);
     int kind = 0;  // 1: residual only, 2: residual + Jacobian + LU
@@ -237,6 +255,7 @@ __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
     }
     __syncthreads();
     wg_copy_words(a.sys + b, s_raw);
+    if (a.f.nrt > 0) wg_copy_root(a.roots + b, &s_rt);
     if (threadIdx.x == 0) {
         a.stepping[b] = stepping ? 1 : 0;
         a.in_newton[b] = kind != 0;
@@ -355,17 +374,20 @@ __global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
     __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
+    __shared__ __align__(16) idahip_root_state s_rt;
     wg_copy_words(s_raw, a.sys + b);
+    if (a.f.nrt > 0) wg_copy_root(&s_rt, a.roots + b);
     __syncthreads();
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
-    const IdaFlow<WgVec> F{a.f, s, v};
+    const IdaFlow<WgVec> F{a.f, s, v, a.f.nrt > 0 ? &s_rt : nullptr};
     bool stepping = a.stepping[b] != 0;
     if (stepping && a.in_newton[b] && !s.newton_retry) stepping = F.attempt_end();
     const long long ground = a.round_base + a.round + 1;
     if (a.f.recycle) stepping = F.after_round_stream(stepping, ground, b, threadIdx.x == 0);
     __syncthreads();
     wg_copy_words(a.sys + b, s_raw);
+    if (a.f.nrt > 0) wg_copy_root(a.roots + b, &s_rt);
     if (threadIdx.x == 0) {
         a.stepping[b] = stepping ? 1 : 0;
         if (stepping) atomicAdd(&a.summary[0], 1);

@@ -16,7 +16,8 @@
 //   Newton::solve         /root/reference/crates/nonlinear/src/newton.rs:51-167 (Q3: break on ConvergenceRecover with a current J)
 //   IdaNLProblem          /root/reference/src/ida_nls.rs:118-266
 //   complete_step         /root/reference/src/impl_complete_step.rs:22-177
-// Not handled here (the host stepper keeps those cases): root finding, IDA_ONE_STEP, host-callback problems, per-step traces.
+// Root finding for the family g_i = y[c_i] - thr_i runs here too (ida_flow.hpp). Not handled here (the host stepper keeps those
+// cases): user root functions, IDA_ONE_STEP, host-callback problems, per-step traces.
 #pragma once
 #include "ida_flow.hpp"
 #include "lu_kernels.hpp"
@@ -40,6 +41,7 @@ struct TinyIdaArgs {
     long long round_base;        // rounds executed before this launch
     double *yout, *ypout;        // [ntout][batch][n] or null: y, y' at every tout reached
     long long* rounds_done;      // [batch] rounds this system took part in during this launch
+    idahip_root_state* roots;    // [batch] or null (f.nrt == 0)
 };
 
 // vector backend of IdaFlow: one thread owns system b (the arithmetic of vector_kernels.hpp, element for element)
@@ -159,6 +161,16 @@ struct TinyVec {
             a.v.yy[vb + i] = y;
             a.v.yp[vb + i] = yp;
         }
+    }
+    // root functions (ida_flow.hpp): one thread owns the system, nothing to synchronise
+    __device__ void sync() const {}
+    __device__ double yy_at(int i) const { return a.v.yy[vb + i]; }
+    __device__ double phi_at(int j, int i) const { return phi(j, i); }
+    __device__ void yy_from_phi01(double f) const {
+        for (int i = 0; i < n; ++i) a.v.yy[vb + i] = phi(0, i) + f * phi(1, i);
+    }
+    __device__ void yy_add_phi1(double f) const {
+        for (int i = 0; i < n; ++i) a.v.yy[vb + i] = a.v.yy[vb + i] + f * phi(1, i);
     }
     __device__ void emit_output(int slot) const {  // the output of the tout just reached (idaens_solve_schedule's hYout / hYPout)
         if (a.yout)
@@ -324,7 +336,9 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
     }
     const long vb = lds_vec ? 0 : gvb, lub = lds_vec ? 0 : (long)b * n * n;
     TinyVec v{a, b, n, vb, gvb};
-    const IdaFlow<TinyVec> F{a.f, s, v};
+    idahip_root_state rs;
+    if (a.f.nrt > 0) rs = ga.roots[b];
+    const IdaFlow<TinyVec> F{a.f, s, v, a.f.nrt > 0 ? &rs : nullptr};
     const TinyNewton<KIND> N{a, s, b, n, vb, lub};
     long long ground = a.round_base;  // global round counter (idaens_stream: every system takes part in every round)
     long long done = 0;
@@ -360,6 +374,7 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
         for (int i = 0; i < n; ++i) ga.piv[gvb + i] = pv[i];
     }
     ga.sys[b] = s;
+    if (a.f.nrt > 0) ga.roots[b] = rs;
     ga.rounds_done[b] = done;
 }
 

@@ -904,7 +904,9 @@ int continue_schedule(idaens* e, SolveCall& C, int b) {
 // 1 = one thread per system (idahip_tiny_solve), 2 = lock-step rounds driven from the device (idahip_round_solve), 0 = host stepper
 int device_ctl_applies(const idaens* e, const SolveCall& C) {
     const int k = idahip_kind(e->ctx);
-    if (!e->device_ctl || e->nrtfn != 0 || C.itask != IDAENS_NORMAL || e->trace_sys >= 0) return 0;
+    if (!e->device_ctl || C.itask != IDAENS_NORMAL || e->trace_sys >= 0) return 0;
+    // root finding on the device: the function family of idaens_set_roots (not a user callback), not in idaens_stream
+    if (e->nrtfn != 0 && (e->rt_fn != nullptr || e->nrtfn > IDAHIP_MAX_ROOTS || C.recycle)) return 0;
     if (e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63)) return 1;
     if (e->n > 8 && e->n <= 1024 && k == IDAHIP_LINEAR_DENSE && idahip_lu_variant(e->ctx) >= 4) return 2;
     if (e->n > 8 && e->n <= 4096 && k == IDAHIP_HEAT1D && idahip_lu_variant(e->ctx) >= 4) return 2;
@@ -938,6 +940,22 @@ int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, 
     call.t0 = e->t0;
     call.start_round = (C.recycle && !e->start_round.empty()) ? e->start_round.data() : nullptr;
     call.round_base = e->total_rounds;
+    // the systems' root state (Ida's ida_glo / ghi / grout / iroots / gactive) goes with the controller records
+    std::vector<idahip_root_state> rstate;
+    std::vector<int32_t> rcomp(e->rt_comp.begin(), e->rt_comp.end());
+    call.nroots = e->nrtfn;
+    call.root_comps = rcomp.data();
+    call.root_thresholds = e->rt_thr.data();
+    call.root_states = nullptr;
+    if (e->nrtfn > 0) {
+        rstate.resize(batch);
+        for (int b = 0; b < batch; ++b)
+            for (int i = 0; i < e->nrtfn; ++i) {
+                rstate[b].glo[i] = S[b].glo[i]; rstate[b].ghi[i] = S[b].ghi[i]; rstate[b].grout[i] = S[b].grout[i];
+                rstate[b].iroots[i] = S[b].iroots[i]; rstate[b].gactive[i] = S[b].gactive[i];
+            }
+        call.root_states = rstate.data();
+    }
     std::vector<int64_t> rounds(batch, 0);
     uint64_t acc[2] = {0, 0};
     std::vector<double> yo, ypo;
@@ -954,6 +972,10 @@ int solve_core_device(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, 
     bool unfinished = false;
     for (int b = 0; b < batch; ++b) {
         static_cast<SysCore&>(S[b]) = st[b];
+        for (int i = 0; i < e->nrtfn; ++i) {
+            S[b].glo[i] = rstate[b].glo[i]; S[b].ghi[i] = rstate[b].ghi[i]; S[b].grout[i] = rstate[b].grout[i];
+            S[b].iroots[i] = rstate[b].iroots[i]; S[b].gactive[i] = (uint8_t)rstate[b].gactive[i];
+        }
         rmax = std::max(rmax, rounds[b]);
         Sys& s = S[b];
         const int now = reached_of(s);

@@ -232,3 +232,52 @@ def test_device_lock_step_rounds_for_the_heat_problem(n, batch, ntout):
         assert np.array_equal(c[k], ref["counters"][k]), k
     assert np.array_equal(c["kused"], ref["kused"]) and np.array_equal(dev.real("hused"), ref["hused"])
     assert dev.total_rounds() >= host.total_rounds() > 0
+
+
+def _run_with_roots(ens, touts, comps, thr, max_returns=400):
+    """Ida::solve until every tout is reached, every return recorded (root returns do not advance the tout)."""
+    ens.set_roots(comps, thr)
+    rec = []
+    for t in touts:
+        for _ in range(max_returns):
+            st, tret = ens.solve(float(t))
+            rec.append((st.copy(), tret.copy(), ens.yy(), ens.yp(), ens.roots_found().copy()))
+            assert (st >= 0).all()
+            if (st == 0).all():
+                break
+        else:
+            raise AssertionError("no end of root returns")
+    return rec
+
+
+@pytest.mark.parametrize("name", ["roberts", "linear_dense"])
+def test_root_finding_on_the_device_steppers(name):
+    """impl_r_check.rs on the device (ida_flow.hpp): the bracketing of idaens_set_roots' function family runs inside the
+    one-thread-per-system stepper (Roberts: the reference example's two functions) and inside the lock-step rounds (linear
+    dense, n = 24: two components crossing half of their final values). Every return -- status, t_ret, y, y', rootsfound --
+    and the counters incl. the root-function evaluations equal the host stepper's, which the oracle pins
+    (tests/test_gpu_ensemble.py::test_roberts_example_with_root_finding)."""
+    from idahip import problems
+    if name == "roberts":
+        prob = roberts_batch(6)
+        touts = [0.4, 4.0, 40.0]
+        comps, thr = [0, 2], [0.97, 0.01]
+    else:
+        prob = problems.linear_dense(n=24, batch=7, procs=1)
+        touts = [float(t) for t in prob["touts"][:4]]
+        c0, plain = make(prob, 0)
+        for t in touts:
+            plain.solve(t)
+        yend = plain.yy()
+        comps = [1, 4]
+        thr = [float(np.median(yend[:, 1])) * 0.5, float(np.median(yend[:, 4])) * 0.5]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    rd = _run_with_roots(dev, touts, comps, thr)
+    rh = _run_with_roots(host, touts, comps, thr)
+    assert len(rd) == len(rh) and any((r[0] == 2).any() for r in rh), "no root return in this run"
+    for a, b in zip(rd, rh):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    same(state(dev), state(host))
+    assert np.array_equal(dev.counter("nge"), host.counter("nge")) and (dev.counter("nge") > 0).all()
