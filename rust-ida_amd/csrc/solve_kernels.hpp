@@ -78,23 +78,36 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         if (wave == 0) {
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
-#pragma unroll 1
-            for (int k0 = 0; k0 + 1 < kw; k0 += UNR) {
-                double lik[UNR];
+            // The columns of the diagonal block come in groups of UNR; the NEXT group is requested before the steps of the current
+            // one run (two register sets). Requested after them, every group was a round trip to memory in the middle of a
+            // 64-step dependent chain: ~10 us per diagonal block, 16 blocks per solve at n = 512 -- the lifetime of a workgroup, and
+            // of every launch that serves few systems (the later Newton iterations of a round).
+            auto ldl = [&](const int k0, double (&l)[UNR]) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 + u;
-                    if (STAGE) lik[u] = (k + 1 < kw && lane > k && lane < kw) ? dg[k * 64 + lane] : 0.0;
-                    else lik[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
+                    if (STAGE) l[u] = (k + 1 < kw && lane > k && lane < kw) ? dg[k * 64 + lane] : 0.0;
+                    else l[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
                 }
+            };
+            auto fwd = [&](const int k0, const double (&l)[UNR]) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 + u;
                     if (k + 1 < kw) {
                         const double bk = readlane_f64(bi, k);
-                        if (lane > k && lane < kw) bi -= lik[u] * bk;
+                        if (lane > k && lane < kw) bi -= l[u] * bk;
                     }
                 }
+            };
+            double la[UNR], lb[UNR];
+            ldl(0, la);
+#pragma unroll 1
+            for (int k0 = 0; k0 + 1 < kw; k0 += 2 * UNR) {
+                ldl(k0 + UNR, lb);  // (past the block's end: every entry is 0.0, no load)
+                fwd(k0, la);
+                ldl(k0 + 2 * UNR, la);
+                fwd(k0 + UNR, lb);
             }
             if (lane < kw) bs[i] = bi;
             if (STAGE) {
@@ -158,24 +171,33 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         if (wave == 0) {
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
-#pragma unroll 1
-            for (int k0 = kw - 1; k0 >= 0; k0 -= UNR) {
-                double uik[UNR];
+            auto ldu = [&](const int k0, double (&uu)[UNR]) {  // (the next group in flight behind the current one's steps, as above)
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 - u;
-                    if (STAGE) uik[u] = (k >= 0 && lane <= k) ? dg[k * 64 + lane] : 1.0;
-                    else uik[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
+                    if (STAGE) uu[u] = (k >= 0 && lane <= k) ? dg[k * 64 + lane] : 1.0;
+                    else uu[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
                 }
+            };
+            auto bwd = [&](const int k0, const double (&uu)[UNR]) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 - u;
                     if (k >= 0) {
-                        if (lane == k) bi = bi / uik[u];
+                        if (lane == k) bi = bi / uu[u];
                         const double bk = readlane_f64(bi, k);
-                        if (lane < k) bi -= uik[u] * bk;
+                        if (lane < k) bi -= uu[u] * bk;
                     }
                 }
+            };
+            double ua[UNR], ub[UNR];
+            ldu(kw - 1, ua);
+#pragma unroll 1
+            for (int k0 = kw - 1; k0 >= 0; k0 -= 2 * UNR) {
+                ldu(k0 - UNR, ub);  // (below column 0: every entry is 1.0, no load)
+                bwd(k0, ua);
+                ldu(k0 - 2 * UNR, ua);
+                bwd(k0 - UNR, ub);
             }
             if (lane < kw) bs[i] = bi;
             if (STAGE) {
