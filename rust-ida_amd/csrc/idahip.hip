@@ -1032,14 +1032,14 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
         KTimer kt(c, IDAHIP_K_VECTOR, batch);
         // LDS: the 64 controller records of a workgroup, and the systems' vectors too when the device grants that much
         const size_t lds_state = 64 * sizeof(idactl::SysCore), lds_all = lds_state + 64 * sizeof(double) * tiny_lds_doubles(n);
-        const void* fn = c->kind == IDAHIP_ROBERTS ? (const void*)tiny_ida_kernel<IDAHIP_ROBERTS> : (const void*)tiny_ida_kernel<IDAHIP_LORENZ63>;
-        const int lds_vec = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) == hipSuccess ? 1 : 0;
+        // four instantiations: problem x (root finding compiled in | out -- the bracketing code costs the plain stepper registers)
+        const bool roots = call->nroots > 0;
+        auto kern = c->kind == IDAHIP_ROBERTS ? (roots ? tiny_ida_kernel<IDAHIP_ROBERTS, true> : tiny_ida_kernel<IDAHIP_ROBERTS, false>)
+                                              : (roots ? tiny_ida_kernel<IDAHIP_LORENZ63, true> : tiny_ida_kernel<IDAHIP_LORENZ63, false>);
+        const int lds_vec = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) == hipSuccess ? 1 : 0;
         if (!lds_vec) (void)hipGetLastError();
         const size_t shm = lds_vec ? lds_all : lds_state;
-        if (c->kind == IDAHIP_ROBERTS)
-            hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_ROBERTS>, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
-        else
-            hipLaunchKernelGGL(tiny_ida_kernel<IDAHIP_LORENZ63>, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
+        hipLaunchKernelGGL(kern, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
         if ((rc = post_launch(c, "tiny_ida"))) return rc;
     }
     IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));
@@ -1151,7 +1151,8 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
         a.first_round = r == 0;
         {
             KTimer kt(c, IDAHIP_K_VECTOR, 0);
-            hipLaunchKernelGGL(round_begin_kernel, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            if (call->nroots > 0) hipLaunchKernelGGL(round_begin_kernel<true>, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            else hipLaunchKernelGGL(round_begin_kernel<false>, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
             hipLaunchKernelGGL(round_lists_kernel, dim3(1), dim3(1024), 0, c->stream, a);
         }
         {   // sys(y0), y <- y0 = 0 (newton.rs:73): without and with the Jacobian (J = B + cj A falls out of the same sweep)
@@ -1193,7 +1194,8 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
         IDAHIP_HIP(c, hipMemsetAsync(a.summary, 0, sizeof(int), c->stream));
         {
             KTimer kt(c, IDAHIP_K_VECTOR, 0);
-            hipLaunchKernelGGL(round_end_kernel, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            if (call->nroots > 0) hipLaunchKernelGGL(round_end_kernel<true>, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
+            else hipLaunchKernelGGL(round_end_kernel<false>, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
             if ((rc = post_launch(c, "round_end"))) return rc;
         }
         if (!call->recycle) {  // one synchronisation per round: does any system still step?

@@ -228,17 +228,18 @@ __device__ __forceinline__ void wg_copy_root(void* dst, const void* src) {
     if (threadIdx.x < (int)(sizeof(idahip_root_state) / 8)) static_cast<unsigned long long*>(dst)[threadIdx.x] = static_cast<const unsigned long long*>(src)[threadIdx.x];
 }
 
+template <bool ROOTS>
 __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
     __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
     __shared__ __align__(16) idahip_root_state s_rt;
     wg_copy_words(s_raw, a.sys + b);
-    if (a.f.nrt > 0) wg_copy_root(&s_rt, a.roots + b);
+    if (ROOTS) wg_copy_root(&s_rt, a.roots + b);
     __syncthreads();
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
-    const IdaFlow<WgVec> F{a.f, s, v, a.f.nrt > 0 ? &s_rt : nullptr};
+    const IdaFlow<WgVec, ROOTS> F{a.f, s, v, ROOTS ? &s_rt : nullptr};
     const long long ground = a.round_base + a.round;
     bool stepping = a.first_round ? F.enter(ground, b) : (a.stepping[b] != 0);
     int kind = 0;  // 1: residual only, 2: residual + Jacobian + LU
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
     }
     __syncthreads();
     wg_copy_words(a.sys + b, s_raw);
-    if (a.f.nrt > 0) wg_copy_root(a.roots + b, &s_rt);
+    if (ROOTS) wg_copy_root(a.roots + b, &s_rt);
     if (threadIdx.x == 0) {
         a.stepping[b] = stepping ? 1 : 0;
         a.in_newton[b] = kind != 0;
@@ -370,24 +371,25 @@ __global__ void round_newton_ctl_kernel(RoundArgs a, int phase) {
 }
 
 // ---- end of a round: the rest of the attempt, the schedule, Ida::new again when streaming, the round's summary
+template <bool ROOTS>
 __global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int b = blockIdx.x;
     __shared__ __align__(16) unsigned char s_raw[sizeof(idactl::SysCore)];
     __shared__ __align__(16) idahip_root_state s_rt;
     wg_copy_words(s_raw, a.sys + b);
-    if (a.f.nrt > 0) wg_copy_root(&s_rt, a.roots + b);
+    if (ROOTS) wg_copy_root(&s_rt, a.roots + b);
     __syncthreads();
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(s_raw);
     WgVec v{a, b, a.v.n, (long)b * a.v.n, sm};
-    const IdaFlow<WgVec> F{a.f, s, v, a.f.nrt > 0 ? &s_rt : nullptr};
+    const IdaFlow<WgVec, ROOTS> F{a.f, s, v, ROOTS ? &s_rt : nullptr};
     bool stepping = a.stepping[b] != 0;
     if (stepping && a.in_newton[b] && !s.newton_retry) stepping = F.attempt_end();
     const long long ground = a.round_base + a.round + 1;
     if (a.f.recycle) stepping = F.after_round_stream(stepping, ground, b, threadIdx.x == 0);
     __syncthreads();
     wg_copy_words(a.sys + b, s_raw);
-    if (a.f.nrt > 0) wg_copy_root(a.roots + b, &s_rt);
+    if (ROOTS) wg_copy_root(a.roots + b, &s_rt);
     if (threadIdx.x == 0) {
         a.stepping[b] = stepping ? 1 : 0;
         if (stepping) atomicAdd(&a.summary[0], 1);

@@ -301,7 +301,7 @@ __host__ __device__ constexpr int tiny_lds_doubles(int n) { return 14 * n + n * 
 // the latency of its own state (scratch and global memory: ~500 cycles a touch; LDS: ~60). The vector code is the same either way: the
 // per-thread copy of the arguments points each field at this thread's block and the offsets vb / lub are zero. Config 2 (Lorenz63, 1024 systems): 26.0 -> 31.0 M iterations/s with the controller
 // record alone.
-template <int KIND>
+template <int KIND, bool ROOTS>
 __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_vec) {
     extern __shared__ __align__(16) unsigned char tiny_sm[];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
     const long vb = lds_vec ? 0 : gvb, lub = lds_vec ? 0 : (long)b * n * n;
     TinyVec v{a, b, n, vb, gvb};
     idahip_root_state rs;
-    if (a.f.nrt > 0) rs = ga.roots[b];
-    const IdaFlow<TinyVec> F{a.f, s, v, a.f.nrt > 0 ? &rs : nullptr};
+    if (ROOTS) rs = ga.roots[b];
+    const IdaFlow<TinyVec, ROOTS> F{a.f, s, v, ROOTS ? &rs : nullptr};
     const TinyNewton<KIND> N{a, s, b, n, vb, lub};
     long long ground = a.round_base;  // global round counter (idaens_stream: every system takes part in every round)
     long long done = 0;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
         for (int i = 0; i < n; ++i) ga.piv[gvb + i] = pv[i];
     }
     ga.sys[b] = s;
-    if (a.f.nrt > 0) ga.roots[b] = rs;
+    if (ROOTS) ga.roots[b] = rs;
     ga.rounds_done[b] = done;
 }
 
