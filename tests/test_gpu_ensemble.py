@@ -307,6 +307,11 @@ def test_roberts_example_with_root_finding():
     c = ens.counters()
     assert (c["nst"] == 362).all() and (c["n_attempts"] == 377).all() and (c["nge"] == 404).all()
     assert (c["nni"] == 537).all() and (c["netf"] == 15).all()
+    # config 1 and the paths where oracle and product follow C IDA instead of the reference's text: never taken
+    # (the five Newton-internal re-setups are the reference's own path, newton.rs:146-152)
+    for k in ("ncfn", "nlufail", "nconv_jcur", "nfail_first"):
+        assert (c[k] == 0).all(), k
+    assert (c["nls_nconvfails"] == 5).all()
 
 
 def test_user_root_function_through_the_host_callback():
