@@ -344,6 +344,22 @@ __device__ __forceinline__ void static_for(F&& f) {
 // one system in nine, and was removed in round 3.)
 __device__ __forceinline__ double upd(double a, double u, double l) { return a - u * l; }
 
+// Raw buffer loads / stores: a per-lane 32-bit byte offset plus a scalar byte offset, no 64-bit vector address arithmetic; a
+// per-lane offset at or beyond the descriptor's size reads +0.0 without touching memory (range check on the vector offset).
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, soffset, 0);
+    return __hiloint2double((int)r.y, (int)r.x);
+}
+
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset, double v) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u d;
+    d.x = (unsigned)__double2loint(v);
+    d.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)voffset, soffset, 0);
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     const int lo = __shfl_xor(__double2loint(v), mask);
     const int hi = __shfl_xor(__double2hiint(v), mask);

@@ -80,20 +80,6 @@ __device__ __forceinline__ double opaque_vgpr(double u) {
     return u;
 }
 
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, soffset, 0);
-    return __hiloint2double((int)r.y, (int)r.x);
-}
-
-__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset, double v) {
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    v2u d;
-    d.x = (unsigned)__double2loint(v);
-    d.y = (unsigned)__double2hiint(v);
-    __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)voffset, soffset, 0);
-}
-
 // LDS-only workgroup barrier: unlike __syncthreads() it does not drain the vector-memory counter, so global stores issued
 // inside a latency-critical loop stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

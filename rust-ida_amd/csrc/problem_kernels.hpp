@@ -101,10 +101,17 @@ __global__ void tiny_jac_kernel(double* mats, const double* __restrict__ yy, con
 // One workgroup (256 threads) per system; thread t owns rows {VEC*t + v + VEC*256*pass}; sweeps columns j ascending.
 // WITH_JAC: the sweep also writes the Newton matrix J = B + cj*A (mul, then add -- as linear_jac_kernel) to Jout, column-
 // major: when the reference's Newton::solve calls setup right after sys (call_lsetup), A and B are read once for both.
+#ifndef IDAHIP_SYS_UNR
+#define IDAHIP_SYS_UNR 16
+#endif
 template <int VEC, bool WITH_JAC>
 __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double* __restrict__ A, const double* __restrict__ Bm,
                                                          const double* __restrict__ C, double* __restrict__ Jout) {
     extern __shared__ __align__(16) double sm[];
+    // columns in flight per thread: 16 x 2 matrices x 16 B = 512 B per thread, 128 KB per workgroup. (8: a lone workgroup -- the
+    // later Newton iterations of a round serve 30-150 systems -- streamed at 35 GB/s and lived 119 us; 16: 72 GB/s, 58 us, and the
+    // full launches gain 5 % at two workgroups per CU instead of four. 12, 20, 24 measured slower.)
+    constexpr int UNR = IDAHIP_SYS_UNR;
     const int n = a.n;
     double* syy = sm;
     double* syp = sm + n;
@@ -135,10 +142,10 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ra[v] = rb[v] = 0.0;
         int j = 0;
-        for (; j + 8 <= n; j += 8) {
-            double av[8][VEC], bv[8][VEC];
+        for (; j + UNR <= n; j += UNR) {
+            double av[UNR][VEC], bv[UNR][VEC];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const double* pa = Ab + (long)(j + u) * n + i;
                 const double* pb = Bb + (long)(j + u) * n + i;
                 if constexpr (VEC == 2) {
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
             }
             if constexpr (WITH_JAC) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < UNR; ++u) {
                     double* pj = Jb + (long)(j + u) * n + i;
                     if constexpr (VEC == 2) {
                         double2 o;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const double ypj = syp[j + u], yyj = syy[j + u];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {

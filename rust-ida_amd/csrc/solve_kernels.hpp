@@ -68,6 +68,12 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         stage_store();
         __syncthreads();
     }
+    // Diagonal blocks from global memory (T = 256): buffer loads whose per-lane offset is out of range for the lanes that take no
+    // part -- they read +0.0 -- instead of a guarded load per column. Eight guarded loads are eight branches; the compiler's
+    // wait-count bookkeeping then gives up and every step of the solve waits for ALL outstanding loads, the next group's
+    // prefetch included: one trip to memory per eight steps, 5 us per diagonal block, 32 blocks per solve at n = 512.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(LU), 0, STAGE ? 0 : n * n * 8, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
     __shared__ int s_kfin;  // the entries of b the running column block multiplies with are all finite
     auto neg_zero = [](double x) { return __double_as_longlong(x) == (long long)0x8000000000000000ull; };
 
@@ -75,7 +81,11 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
 #pragma unroll 1
     for (int kb = 0; kb < n; kb += 64) {
         const int kw = (n - kb) < 64 ? (n - kb) : 64;
+#ifdef IDAHIP_EXP_NODIAG  // timing builds (wrong results), -DIDAHIP_EXP_NODIAG / -DIDAHIP_EXP_NOSWEEP: the solve without its diagonal blocks / its sweeps
+        if (false) {
+#else
         if (wave == 0) {
+#endif
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
             // The columns of the diagonal block come in groups of UNR; the NEXT group is requested before the steps of the current
@@ -87,7 +97,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 + u;
                     if (STAGE) l[u] = (k + 1 < kw && lane > k && lane < kw) ? dg[k * 64 + lane] : 0.0;
-                    else l[u] = (k + 1 < kw && lane > k && lane < kw) ? LU[(long)(kb + k) * n + i] : 0.0;
+                    else l[u] = buf_load_f64(rsrc, (k + 1 < kw && lane > k && lane < kw) ? (unsigned)i * 8u : OOB, __builtin_amdgcn_readfirstlane((kb + k) * n * 8));
                 }
             };
             auto fwd = [&](const int k0, const double (&l)[UNR]) {
@@ -120,7 +130,11 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         const bool kfin = zk != nullptr && s_kfin != 0;
         const int ibeg = kb + 64;
         if (STAGE && ibeg < n) stage_load(ibeg);  // the next diagonal block, in flight behind the sweep
+#ifdef IDAHIP_EXP_NOSWEEP
+        if (false) {
+#else
         if (ibeg < n) {  // rows below a full 64-column block
+#endif
 #pragma unroll 1
             for (int i = ibeg + VEC * t; i < n; i += VEC * T) {
                 double acc[VEC];
@@ -168,7 +182,11 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int kb = blk * 64;
         const int kw = (n - kb) < 64 ? (n - kb) : 64;
+#ifdef IDAHIP_EXP_NODIAG
+        if (false) {
+#else
         if (wave == 0) {
+#endif
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
             auto ldu = [&](const int k0, double (&uu)[UNR]) {  // (the next group in flight behind the current one's steps, as above)
@@ -176,7 +194,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 - u;
                     if (STAGE) uu[u] = (k >= 0 && lane <= k) ? dg[k * 64 + lane] : 1.0;
-                    else uu[u] = (k >= 0 && lane <= k) ? LU[(long)(kb + k) * n + i] : 1.0;
+                    else uu[u] = buf_load_f64(rsrc, (k >= 0 && lane <= k) ? (unsigned)i * 8u : OOB, __builtin_amdgcn_readfirstlane((kb + (k >= 0 ? k : 0)) * n * 8));  // (0.0 where 1.0 stood: never used)
                 }
             };
             auto bwd = [&](const int k0, const double (&uu)[UNR]) {
@@ -209,7 +227,11 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         const unsigned char* zk = (STAGE && zmap) ? zmap + (kb >> 6) * 64 : nullptr;
         const bool kfin = zk != nullptr && s_kfin != 0;
         if (STAGE && kb > 0) stage_load(kb - 64);
+#ifdef IDAHIP_EXP_NOSWEEP
+        if (false) {
+#else
         if (kb > 0) {
+#endif
 #pragma unroll 1
             for (int i = VEC * t; i < kb; i += VEC * T) {  // kb is a multiple of 64 (hence even): i + v < kb
                 double acc[VEC];
