@@ -238,6 +238,10 @@ int idahip_round_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idah
  * Any other value is refused. (Round 2's variant 5, the same kernels with FMA-contracted updates, is gone: DESIGN.md.) */
 int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
 int idahip_lu_variant(const idahip_ctx* ctx); /* the variant in force */
+/* 0 for the product library. 1 for a TIMING BUILD (-DIDAHIP_TIMING_BUILD, rust-ida_amd/csrc/exp_switches.hpp): a library in
+ * which parts of kernels were removed or replaced to measure what they cost -- its results are garbage by design; a caller
+ * that cares (tests, bench.py) refuses to run on one. No ctx, no device needed. */
+int idahip_timing_build(void);
 
 /* ---- measurement hooks (bench.py / profiles): device time of the launches of the last call, by HIP events on the
  * ctx stream, and launch counters per kernel class ---- */

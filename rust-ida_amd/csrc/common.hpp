@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/ida_hip.h"
+#include "exp_switches.hpp"
 
 namespace idahip {
 

@@ -21,7 +21,7 @@
 
 #include "glibc_pow_tables.hpp"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GLIBC_POW_HD __host__ __device__
 #else
 #define GLIBC_POW_HD

@@ -1225,13 +1225,14 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
 }
 
 int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
+int idahip_timing_build(void) { return tb::TIMING_BUILD ? 1 : 0; }
 
 // LSolver::get_type / num_iters / res_norm of the dense direct solver (crates/linear/src/dense.rs:30-36, traits.rs:82-90)
 int idahip_ls_type(const idahip_ctx* c) { return c ? IDAHIP_LS_DIRECT : -1; }
 int idahip_ls_num_iters(const idahip_ctx* c) { return c ? 0 : -1; }
 double idahip_ls_res_norm(const idahip_ctx* c) { (void)c; return 0.0; }
 
-#ifdef IDAHIP_STAMPS
+#ifdef IDAHIP_STAMPS /* (only accepted together with -DIDAHIP_TIMING_BUILD: exp_switches.hpp) */
 /* timing builds: a device buffer for in-kernel time stamps (8 per workgroup of the instrumented launch) */
 void* idahip_debug_stamps(idahip_ctx* c, size_t words) {
     if (!c) return nullptr;

@@ -365,12 +365,9 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
     __shared__ int s_r[2][NW];
     __shared__ int s_cnt[R][NW];
 
-#ifdef IDAHIP_STAMPS
-    unsigned long long* st = (k0 == 0 && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
-#define STAMP(i) do { if (st && t == 0) st[i] = wall_clock64(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
+    // (timing builds only, exp_switches.hpp: tb::STAMPS is -1 in the product and everything below folds away)
+    unsigned long long* st = (tb::STAMPS >= 0 && k0 == 0 && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#define STAMP(i) do { if (tb::STAMPS >= 0 && st && t == 0) st[i] = wall_clock64(); } while (0)
     STAMP(0);
     if (t < 32) {  // slots of waves that do not exist in this launch never win
         (&s_kh[0][0])[t] = 0u;
@@ -526,9 +523,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_panelr_kernel(LuWs w, int k0, in
 #pragma unroll
             for (int j = k + 1; j < NB; ++j) a[i][j] = uz[j] ? a[i][j] : a[i][j] - u[j] * aik;  // dense.rs:148-151
         }
-#ifdef IDAHIP_STAMPS
         if (k < 4) STAMP(4 + k);
-#endif
         return true;
     };
     failed = !static_steps<0, NB>(step, wd);
@@ -907,11 +902,7 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(LuWs w, int k0, int nsys,
 template <int MAXROWS>
 __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kernel(LuWs w, int k0, int nsys, int ncb, int nsplit_arg) {
     constexpr int NB = 64, KC = 32;
-#ifdef IDAHIP_EXP_NOPRO
-    constexpr bool NOPRO = true;  // timing build: no gather, no U12 solve (U12 = constants); results are garbage
-#else
-    constexpr bool NOPRO = false;
-#endif
+    constexpr bool NOPRO = tb::NOPRO;  // timing build (exp_switches.hpp): no gather, no U12 solve (U12 = constants); false in the product
     const int nsplit = MAXROWS > 1024 ? nsplit_arg : 1;  // the row split exists for large n only
     // workgroups of one matrix: its ncb column blocks, then (nsplit > 1) nsplit - 1 helpers for each of the first
     // LU_SPLIT_BLOCKS column blocks
@@ -956,20 +947,13 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int pl = 4 * (lane & 15) + (lane >> 4);  // LDS slot of column `lane`: columns q, q+16, q+32, q+48 sit together
-#ifdef IDAHIP_STAMPS
-    unsigned long long* tst = (k0 == IDAHIP_STAMPS && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
-#define TSTAMP(i) do { if (tst && t == 0) tst[i] = wall_clock64(); } while (0)
-#else
-#define TSTAMP(i) do { } while (0)
-#endif
+    unsigned long long* tst = (tb::STAMPS >= 0 && k0 == tb::STAMPS && w.stamps) ? w.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#define TSTAMP(i) do { if (tb::STAMPS >= 0 && tst && t == 0) tst[i] = wall_clock64(); } while (0)
     TSTAMP(0);
 
-#ifndef IDAHIP_US_PAD
-#define IDAHIP_US_PAD 2
-#endif
     // U12, columns permuted by pl. Rows padded by two doubles (still 16-byte aligned for ds_read_b128): the column reads of
     // the store to the factors below (lane = row) then spread over 8 bank groups instead of hitting one
-    __shared__ __align__(16) double Us[NB][64 + IDAHIP_US_PAD];
+    __shared__ __align__(16) double Us[NB][64 + tb::US_PAD];
     __shared__ __align__(16) double Ls[KC][64];      // prologue: L11 staging; update loop: 4 wave-private [KC][16] strips
     __shared__ unsigned short s_live[MAXROWS];
     __shared__ int s_anyzero;
@@ -1031,10 +1015,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     // way and, if one was zero, nothing has been stored: the prologue below starts over with the rule applied per entry.
     __shared__ int s_fz[4];
     bool fast_ok = false;
-#ifndef IDAHIP_TRAIL_QUAD
-#define IDAHIP_TRAIL_QUAD 1
-#endif
-    if constexpr (MAXROWS <= 1024 && IDAHIP_TRAIL_QUAD != 0) {
+    if constexpr (MAXROWS <= 1024 && tb::TRAIL_QUAD) {
       if (!NOPRO) {
         const int part = lane & 3, qc = wave * 16 + (lane >> 2);
         const bool real = qc < ncols;
@@ -1047,11 +1028,8 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             for (int i = 0; i < 16; ++i) {
                 const int p0 = ldc(prow + 4 * i), p1 = ldc(prow + 4 * i + 1), p2 = ldc(prow + 4 * i + 2), p3 = ldc(prow + 4 * i + 3);
                 const int pr = part == 0 ? p0 : part == 1 ? p1 : part == 2 ? p2 : p3;
-#ifdef IDAHIP_EXP_NOGATHER
-                u[i] = 1.0e-3 * (double)(1 + ((i + pr) & 7));  // timing build
-#else
-                u[i] = colp[pr];
-#endif
+                if constexpr (tb::NOGATHER) u[i] = 1.0e-3 * (double)(1 + ((i + pr) & 7));  // timing build
+                else u[i] = colp[pr];
             }
         }
         double* __restrict__ Lq = &Us[0][0];  // [64][66]: row kk, entry of pivot row k at (k & 3) * 16 + (k >> 2) + 2 * ((k & 3) >> 1)
@@ -1266,9 +1244,7 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
             if (cc < ncols) O[(long)(cb0 + cc) * n + k0 + lane] = Us[lane][4 * (cc & 15) + (cc >> 4)];
         }
     }
-#ifdef IDAHIP_EXP_NOUPD
-    return;  // timing build: prologue only
-#endif
+    if constexpr (tb::NOUPD) return;  // timing build: prologue only
     TSTAMP(4);
     const unsigned kmask0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[0]);
     const unsigned kmask1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_kmask[1]);
@@ -1322,27 +1298,24 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
                     for (int i = 0; i < 4; ++i) c[i][j] = upd(c[i][j], uv[j], lv[i]);  // dense.rs:151
             };
-#ifndef IDAHIP_TRAIL_PIPE
-#define IDAHIP_TRAIL_PIPE 1
-#endif
-#if IDAHIP_TRAIL_PIPE
-            rd(0, lvA, uvA);
+            if constexpr (tb::TRAIL_PIPE) {
+                rd(0, lvA, uvA);
 #pragma unroll
-            for (int k = 0; k < KC; k += 2) {
-                rd(k + 1, lvB, uvB);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(lvA, uvA);
-                if (k + 2 < KC) rd(k + 2, lvA, uvA);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(lvB, uvB);
-            }
-#else
+                for (int k = 0; k < KC; k += 2) {
+                    rd(k + 1, lvB, uvB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(lvA, uvA);
+                    if (k + 2 < KC) rd(k + 2, lvA, uvA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(lvB, uvB);
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                rd(k, lvA, uvA);
-                mac(lvA, uvA);
+                for (int k = 0; k < KC; ++k) {
+                    rd(k, lvA, uvA);
+                    mac(lvA, uvA);
+                }
             }
-#endif
         } else {
             for (unsigned mk = kbase == 0 ? kmask0 : kmask1; mk != 0u; mk &= mk - 1u) {  // ascending k, all-zero pivot rows skipped
                 const int k = __builtin_ctz(mk);
@@ -1377,13 +1350,13 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[i][j] = creg[i][j];
         }
-#ifdef IDAHIP_STAMPS
-        if (s == s0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TSTAMP(5); }
-#endif
+        if constexpr (tb::STAMPS >= 0) {
+            if (s == s0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TSTAMP(5); }
+        }
         chunk(c, 0);
-#ifdef IDAHIP_STAMPS
-        if (s == s0) TSTAMP(6);
-#endif
+        if constexpr (tb::STAMPS >= 0) {
+            if (s == s0) TSTAMP(6);
+        }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) Lw[4 * i + kq][lslot] = lreg[i];  // same wave, program order: chunk 0's reads are done
         if (s + sstep < nstrips) {  // next strip in flight behind the second chunk

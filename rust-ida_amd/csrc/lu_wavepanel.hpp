@@ -31,13 +31,10 @@
 namespace idahip {
 
 constexpr int WP_MAX_ROWS = 512;
-#ifndef IDAHIP_WP_RING
-#define IDAHIP_WP_RING 0
-#endif
 // depth (in pivots) of the multiplier prefetch ring of lu_wavepanel_kernel for a given slot count
 // (measured, 1240 matrices per call: rings of 4 and 8 change nothing for 1-5 slots and cost 4-8 % for 6-7 -- the loop waits
-// for instruction issue, not for the loads; IDAHIP_WP_RING=1 builds the deep rings for another look)
-constexpr int WP_RING(int ns) { return !IDAHIP_WP_RING ? 2 : (ns >= 1 && ns <= 2) ? 8 : (ns >= 3 && ns <= 7) ? 4 : 2; }  // 8 slots of 64 lanes
+// for instruction issue, not for the loads; -DIDAHIP_TIMING_BUILD -DIDAHIP_WP_RING=1 builds the deep rings for another look)
+constexpr int WP_RING(int ns) { return !tb::WP_DEEP_RING ? 2 : (ns >= 1 && ns <= 2) ? 8 : (ns >= 3 && ns <= 7) ? 4 : 2; }  // 8 slots of 64 lanes
 
 // NS > 0: the number of slots (= ceil(live rows / 64)) as a compile-time constant -- the per-slot guards fold away and the
 // registers of the unused slots are never allocated (eight instantiations of the FAST kernel, one per super-panel of an

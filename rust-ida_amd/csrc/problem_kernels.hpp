@@ -101,9 +101,6 @@ __global__ void tiny_jac_kernel(double* mats, const double* __restrict__ yy, con
 // One workgroup (256 threads) per system; thread t owns rows {VEC*t + v + VEC*256*pass}; sweeps columns j ascending.
 // WITH_JAC: the sweep also writes the Newton matrix J = B + cj*A (mul, then add -- as linear_jac_kernel) to Jout, column-
 // major: when the reference's Newton::solve calls setup right after sys (call_lsetup), A and B are read once for both.
-#ifndef IDAHIP_SYS_UNR
-#define IDAHIP_SYS_UNR 16
-#endif
 template <int VEC, bool WITH_JAC>
 __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double* __restrict__ A, const double* __restrict__ Bm,
                                                          const double* __restrict__ C, double* __restrict__ Jout) {
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(256) void linear_sys_kernel(SysArgs a, const double
     // columns in flight per thread: 16 x 2 matrices x 16 B = 512 B per thread, 128 KB per workgroup. (8: a lone workgroup -- the
     // later Newton iterations of a round serve 30-150 systems -- streamed at 35 GB/s and lived 119 us; 16: 72 GB/s, 58 us, and the
     // full launches gain 5 % at two workgroups per CU instead of four. 12, 20, 24 measured slower.)
-    constexpr int UNR = IDAHIP_SYS_UNR;
+    constexpr int UNR = tb::SYS_UNR;
     const int n = a.n;
     double* syy = sm;
     double* syp = sm + n;

@@ -81,11 +81,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
 #pragma unroll 1
     for (int kb = 0; kb < n; kb += 64) {
         const int kw = (n - kb) < 64 ? (n - kb) : 64;
-#ifdef IDAHIP_EXP_NODIAG  // timing builds (wrong results), -DIDAHIP_EXP_NODIAG / -DIDAHIP_EXP_NOSWEEP: the solve without its diagonal blocks / its sweeps
-        if (false) {
-#else
-        if (wave == 0) {
-#endif
+        if (!tb::NODIAG && wave == 0) {  // (tb::NODIAG / tb::NOSWEEP: timing builds of exp_switches.hpp, false in the product)
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
             // The columns of the diagonal block come in groups of UNR; the NEXT group is requested before the steps of the current
@@ -130,11 +126,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         const bool kfin = zk != nullptr && s_kfin != 0;
         const int ibeg = kb + 64;
         if (STAGE && ibeg < n) stage_load(ibeg);  // the next diagonal block, in flight behind the sweep
-#ifdef IDAHIP_EXP_NOSWEEP
-        if (false) {
-#else
-        if (ibeg < n) {  // rows below a full 64-column block
-#endif
+        if (!tb::NOSWEEP && ibeg < n) {  // rows below a full 64-column block
 #pragma unroll 1
             for (int i = ibeg + VEC * t; i < n; i += VEC * T) {
                 double acc[VEC];
@@ -182,11 +174,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int kb = blk * 64;
         const int kw = (n - kb) < 64 ? (n - kb) : 64;
-#ifdef IDAHIP_EXP_NODIAG
-        if (false) {
-#else
-        if (wave == 0) {
-#endif
+        if (!tb::NODIAG && wave == 0) {
             const int i = kb + lane;
             double bi = (lane < kw) ? bs[i] : 0.0;
             auto ldu = [&](const int k0, double (&uu)[UNR]) {  // (the next group in flight behind the current one's steps, as above)
@@ -227,11 +215,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
         const unsigned char* zk = (STAGE && zmap) ? zmap + (kb >> 6) * 64 : nullptr;
         const bool kfin = zk != nullptr && s_kfin != 0;
         if (STAGE && kb > 0) stage_load(kb - 64);
-#ifdef IDAHIP_EXP_NOSWEEP
-        if (false) {
-#else
-        if (kb > 0) {
-#endif
+        if (!tb::NOSWEEP && kb > 0) {
 #pragma unroll 1
             for (int i = VEC * t; i < kb; i += VEC * T) {  // kb is a multiple of 64 (hence even): i + v < kb
                 double acc[VEC];

@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots", "idaens_set_root_fn",
@@ -71,6 +71,10 @@ def load():
             raise OSError("%s is missing: the HIP extension is not built (run `python __graft_entry__.py`); "
                           "there is no CPU fallback" % p)
     H = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
+    H.idahip_timing_build.argtypes = []
+    if H.idahip_timing_build() != 0 and os.environ.get("IDAHIP_ALLOW_TIMING_BUILD") != "1":
+        raise OSError("%s is a timing build (-DIDAHIP_TIMING_BUILD, csrc/exp_switches.hpp): its results are garbage by design; "
+                      "only the measurement tools load one, with IDAHIP_ALLOW_TIMING_BUILD=1" % LIB_HIP)
     E = C.CDLL(LIB_ENS)
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     H.idahip_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp]

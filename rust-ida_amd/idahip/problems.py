@@ -88,6 +88,18 @@ def _fill_range(args):
 
 
 
+def ensure_fork_server():
+    """Start multiprocessing's fork server now (idempotent). The server is started by fork + exec of a fresh interpreter; call
+    this BEFORE the process creates its first device context, so that the exec never comes from a process that holds an
+    initialised ROCm runtime (the generator pools of linear_dense / linear_dense_slices then fork from the clean server)."""
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    ctx = mp.get_context("forkserver")
+    ctx.set_forkserver_preload(["numpy"])
+    forkserver.ensure_running()
+    return ctx
+
+
 def linear_dense(n=512, batch=4096, first=0, procs=1, nthreads=1):
     """Config 3/5 -- synthetic random linear dense index-1 DAE F = A y' + B y - c, systems [first, first+batch).
     Matrices are returned column-major per system (array[s, j, i] = M_s(i, j)).
@@ -204,6 +216,8 @@ def make_ctx_linear_dense_streamed(n, batch, first=0, procs=1, device=0, stream=
     slice at a time (linear_dense_slices). Returns (ctx, prob): prob has everything linear_dense returns except that "A" and
     "B" only hold the first `keep` systems (the calibration sample / the CPU baseline's sample)."""
     from . import Ctx
+    if procs > 1 and batch >= 2 * procs:
+        ensure_fork_server()  # before the device context exists: the server's exec must not come from a GPU process
     ctx = Ctx("linear_dense", n, batch, device=device, stream=stream)
     rtol, atol = 1.0e-6, np.array([1.0e-8])
     ctx.set_tolerances(rtol, atol)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Development tool (round 5, VERDICT r4 next #1a): config 3 as ONE ensemble of B systems on one stream against TWO ensembles
+of B/2 systems on two streams driven by two host threads, the second started half a round later -- does one half's
+latency-bound part of a lock-step round (panel kernels' serial chain, Newton passes 2-4, round begin/end) run under the other
+half's full launches?   usage: python tools/half_streams.py [B] [rounds]"""
+import ctypes as C, os, sys, time, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rust-ida_amd"))
+import numpy as np
+import idahip
+from idahip import problems
+
+hip = C.CDLL("libamdhip64.so")
+PROCS = int(os.environ.get("IDAHIP_GEN_PROCS", "16"))
+
+
+def mkstream():
+    s = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(s), C.c_uint(1)) == 0  # hipStreamNonBlocking
+    return s
+
+
+class Half:
+    def __init__(self, n, batch, first, stagger, stream):
+        self.ctx, self.prob = problems.make_ctx_linear_dense_streamed(n, batch, first=first, procs=PROCS, stream=stream)
+        self.ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
+        self.ens.stream(self.prob["touts"], max(200, 3 * stagger), stagger_rounds=stagger)
+
+    def run(self, k):
+        self.ens.stream(self.prob["touts"], k)
+
+    def iters(self):
+        return self.ens.total_newton_iters()
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    n, stagger = 512, 62
+    if PROCS > 1:
+        problems.ensure_fork_server()  # before anything touches the GPU
+    hip.hipInit(0)
+    hip.hipSetDevice(0)
+    one = Half(n, B, 0, stagger, mkstream())
+    for rep in range(3):
+        i0 = one.iters(); t0 = time.perf_counter(); one.run(K); dt = time.perf_counter() - t0
+        print("one ensemble of %d: %d rounds %.1f ms/round, %.1f k iters/s" % (B, K, dt / K * 1e3, (one.iters() - i0) / dt / 1e3), flush=True)
+    one.ens.close(); one.ctx.close(); del one
+    halves = [Half(n, B // 2, 0, stagger, mkstream()), Half(n, B // 2, B // 2, stagger, mkstream())]
+    for h in halves:  # each half alone
+        i0 = h.iters(); t0 = time.perf_counter(); h.run(K); dt = time.perf_counter() - t0
+        print("half of %d alone: %.1f ms/round, %.1f k iters/s" % (B // 2, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
+    for delay_ms in (0.0, 4.0, 8.0):
+        for rep in range(2):
+            i0 = sum(h.iters() for h in halves)
+
+            def go(h, d):
+                if d > 0:
+                    time.sleep(d * 1e-3)
+                h.run(K)
+            th = [threading.Thread(target=go, args=(halves[0], 0.0)), threading.Thread(target=go, args=(halves[1], delay_ms))]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            dt = time.perf_counter() - t0
+            print("two halves on two streams, second %.0f ms late: %.1f ms per round of both, %.1f k iters/s" %
+                  (delay_ms, dt / K * 1e3, (sum(h.iters() for h in halves) - i0) / dt / 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,5 @@
 #!/bin/bash
+export IDAHIP_ALLOW_TIMING_BUILD=1  # these tools compare builds, timing builds (-DIDAHIP_TIMING_BUILD -DIDAHIP_EXP_...) among them
 # Development tool (GPU box): rocprofv3 kernel trace of tools/panel_time.py, per-launch durations of the LU kernels.
 # usage: [IDAHIP_LIB_HIP=...] tools/kt.sh <tag> [batch] [round-dir, default r4]
 TAG=$1; B=${2:-1370}; RD=${3:-r4}

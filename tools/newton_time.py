@@ -6,7 +6,7 @@ from idahip import problems
 
 def main():
     n, B = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    p = problems.linear_dense(n=n, batch=B, procs=16)
+    p = problems.linear_dense(n=n, batch=B, procs=int(os.environ.get("IDAHIP_GEN_PROCS", "16")))
     ctx = problems.make_ctx(p)
     ctx.upload(idahip.F_YY, p["yy0"]); ctx.upload(idahip.F_YP, p["yp0"])
     ctx.upload(idahip.F_EWT, np.ones_like(p["yy0"]))
