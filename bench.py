@@ -30,6 +30,7 @@ Multi-GPU (config 5): the ensemble shards embarrassingly -- rank r integrates sy
 collective; the ranks meet over gloo on CPU tensors for the barrier and the max-over-ranks of the time (no RCCL).
 """
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -232,11 +233,23 @@ class Runner:
         self.ctx.timing(0)
         c = ens.counters()
         out = {"seconds": dt, "iters": ens.total_newton_iters(), "rounds": ens.total_rounds(), "tim": tim,
-               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy(),
+               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy(), "yp": ens.yp(),
+               "stepper": ens.device_controller_active(),
                "paths": {k: int(c[k].sum()) for k in ("ncfn", "nls_nconvfails", "nlufail", "nconv_jcur", "nfail_first", "nge")}}
         ens.close()
         self.ctx.set_lu_variant(4)
         return out
+
+
+def device_record(torch, local_rank):
+    """Which device a rank really ran on (the N > 1 line carries one per rank: two ranks on one card would show here)."""
+    pr = torch.cuda.get_device_properties(local_rank)
+    rec = {"local_rank": int(local_rank), "name": pr.name, "total_memory_GiB": round(pr.total_memory / 2 ** 30, 1)}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "gcnArchName"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            rec[k] = str(v)
+    return rec
 
 
 def cpu_baseline(prob_small, cores):
@@ -342,6 +355,10 @@ def main():
                     help="linear_dense = config 3 (the headline, N=512 B=4096); heat1d = config 4 (N=4096 B=256); lorenz63 = config 2 (N=3 B=1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-pass figures (N = 1 extras)")
+    ap.add_argument("--passes", type=int, default=10, help="whole passes timed for `whole_pass` (SURVEY 8(d): >= 10 repetitions on fresh state, median)")
+    ap.add_argument("--results-npz", default=None,
+                    help="rank 0 writes the concatenated per-system results of the ensemble's verification pass (nst, nni, y(tout), y'(tout) in "
+                         "global system order, SURVEY 8(e): 'host concatenates') to this file")
     ap.add_argument("--inputs-only", action="store_true",
                     help="host-side rehearsal of an N-rank start: every rank generates its shard (slice by slice, as for the upload), "
                          "rank 0 collects and prints seconds and peak resident memory per rank; no GPU is touched (torch is not imported)")
@@ -359,8 +376,15 @@ def main():
 
     # ---- inputs (numpy worker processes of a fork server; nothing of the GPU is loaded yet)
     from idahip import problems, sharding
-    cores = os.cpu_count() or 1
+    # the cores this process may run on (a launcher or a container may have pinned it): the N ranks of a node start their
+    # generator processes at the same time, so each takes its share of those cores and at most 16
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
     procs = int(os.environ.get("IDAHIP_GEN_PROCS", max(1, min(16, cores // max(1, world)))))  # 1 = in-process (use under rocprofv3)
+    if procs > 1:
+        problems.ensure_fork_server()  # before anything of the GPU is loaded in this process
     t0 = time.time()
     first, count = sharding.shard_range(rank, world, args.batch)
     stream_ctx = None
@@ -438,9 +462,33 @@ def main():
     if TIME_ALL:
         tim = tim2  # the timers were never reset: both are totals over every launch of the process
 
+    # ---- "each shard D2H-copies y(tout), y'(tout) and counters; host concatenates". Untimed: every rank
+    # integrates its shard once from fresh state through the whole output schedule (a result that does not depend on how
+    # the ensemble is sharded, unlike the state of a stream after K rounds; it reuses the stream's device context, so it comes
+    # after everything that continues the stream), rank 0 gathers digests of every rank's block
+    # and its counter sums -- a shard with wrong inputs or a wrong device shows here -- and, on request, the arrays themselves.
+    vp = run.whole_pass(4)
+    vcnt = vp["counts"]  # rows: nst, netf, ncfn, nni, nsetups, kused
+    shard = {"rank": rank, "first": first, "count": count, "device": device_record(torch, local_rank),
+             "input_generation_s": round(t_gen, 1), "sum_nst": int(vcnt[0].sum()), "sum_nni": int(vcnt[3].sum()), "sum_nsetups": int(vcnt[4].sum()),
+             "sha256_yy": hashlib.sha256(np.ascontiguousarray(vp["yy"]).tobytes()).hexdigest(),
+             "sha256_counters": hashlib.sha256(np.ascontiguousarray(vcnt).tobytes()).hexdigest()}
+    shards = [shard]
+    blocks = [(vcnt, vp["yy"], vp["yp"])] if args.results_npz else None
+    if world > 1:
+        shards = [None] * world
+        dist.all_gather_object(shards, shard)
+        if args.results_npz:
+            blocks = [None] * world
+            dist.all_gather_object(blocks, (vcnt, vp["yy"], vp["yp"]))
+    if rank == 0 and args.results_npz:
+        np.savez(args.results_npz, first=np.array([sh["first"] for sh in shards]), counts=np.concatenate([b[0] for b in blocks], axis=1),
+                 yy=np.concatenate([b[1] for b in blocks], axis=0), yp=np.concatenate([b[2] for b in blocks], axis=0))
+
+
     extras = None
     if world == 1 and not args.no_extras:
-        passes = [run.whole_pass(4) for _ in range(3)]
+        passes = [vp] + [run.whole_pass(4) for _ in range(max(1, args.passes) - 1)]
         rates = [p["iters"] / p["seconds"] for p in passes]
         # the same passes with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
         # device-side convergence tests (first slice); identical work and results, only the pace changes
@@ -457,8 +505,9 @@ def main():
             "whole_pass": {"value": statistics.median(rates), "unit": "Newton iters/s", "passes": [round(r, 1) for r in rates],
                            "newton_iters_per_pass": passes[0]["iters"], "rounds_per_pass": passes[0]["rounds"],
                            "seconds_median": statistics.median(p["seconds"] for p in passes),
+                           "stepper": {0: "host lock-step", 1: "device, one thread per system", 2: "device lock-step rounds"}[passes[0]["stepper"]],
                            "protocol": "SURVEY 8(d): every system from fresh state through its whole output schedule, exact LU, "
-                                       "median of 3 passes, wall time of the pass with inputs resident"},
+                                       "median of %d passes, wall time of the pass with inputs resident" % len(passes)},
             "newton_fusion": {"whole_pass_value_with_host_ctest_every_iteration": statistics.median(unfused_rates), "unit": "Newton iters/s",
                               "note": "host stepper with one host round trip per Newton iteration (idaens_set_fused_newton(0) on top of "
                                       "idaens_set_device_controller(0)): round 1's control flow; same work, same results, median of 3 passes"},
@@ -557,7 +606,17 @@ def main():
                        "sharding": "independent systems, contiguous block per rank, no collective"},
             "newton_iters_timed": iters_all,
             "per_rank": None if world == 1 else {"newton_iters": [p[0] for p in per_rank], "seconds": [p[1] for p in per_rank],
+                                                 "input_generation_s": [sh["input_generation_s"] for sh in shards],
+                                                 "devices": [sh["device"] for sh in shards],
+                                                 "generator_processes": procs, "cores_available_to_rank0": cores,
                                                  "process_group": backend + " (barrier and two scalars only; no data-path collective)"},
+            "ensemble_result": {
+                "systems": sum(sh["count"] for sh in shards), "shards": [{k: sh[k] for k in ("rank", "first", "count", "sum_nst", "sum_nni", "sum_nsetups", "sha256_yy", "sha256_counters")} for sh in shards],
+                "sum_nst": sum(sh["sum_nst"] for sh in shards), "sum_nni": sum(sh["sum_nni"] for sh in shards),
+                "note": "SURVEY 8(e): every rank integrates its shard once from fresh state through the whole schedule (untimed) and rank 0 "
+                        "concatenates: digests of y(tout) and of the counters (nst, netf, ncfn, nni, nsetups, kused) per shard, in rank = global "
+                        "system order; --results-npz writes the concatenated arrays (tests/test_gpu_bench_ranks.py compares them with a "
+                        "single-process run)"},
             "roofline": roof,
             "kernel_classes_rank0": classes,
             "lu_kernels_rank0": lu_kernels,

@@ -539,11 +539,20 @@ impl HipEnsemble {
         self.ctx.set_lu_variant(variant)
     }
 
-    /// Small device problems (n <= 8): the whole of `Ida::solve` in one launch with the controller on the device (default on).
-    pub fn set_device_controller(&mut self, on: bool) {
-        unsafe {
-            sys::idaens_set_device_controller(self.raw, on as c_int);
+    /// The device-resident steppers (default on) or the lock-step host stepper. `Err` when the library refuses to switch them
+    /// on: its device `pow` does not have this host's `powf` bits, or the self-check could not run (`last_error` says which).
+    pub fn set_device_controller(&mut self, on: bool) -> Result<(), Error> {
+        let rc = unsafe { sys::idaens_set_device_controller(self.raw, on as c_int) };
+        if rc == 0 {
+            Ok(())
+        } else {
+            Err(Error::Library { code: rc, message: self.last_error() })
         }
+    }
+
+    /// 0 = host stepper, 1 = device stepper with one thread per system, 2 = device lock-step rounds: what `solve` would run on.
+    pub fn device_controller_active(&self) -> i32 {
+        unsafe { sys::idaens_device_controller_active(self.raw) as i32 }
     }
 }
 

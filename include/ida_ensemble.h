@@ -72,6 +72,10 @@ int idaens_set_fused_newton(idaens* e, int on);
  * ranges once per process: if they differ (another libm than the one glibc_pow.hpp restates) the device steppers stay off,
  * idaens_last_error says so and this call returns 1 for on != 0. */
 int idaens_set_device_controller(idaens* e, int on);
+/* Which stepper an idaens_solve / _solve_schedule call (IDAENS_NORMAL) of this ensemble would run on as things stand:
+ * 0 = the host stepper, 1 = the device stepper with one thread per system (n <= 8), 2 = the device lock-step rounds. A test
+ * or a benchmark that means to measure a device stepper asserts this instead of trusting the setter. */
+int idaens_device_controller_active(const idaens* e);
 /* Root finding (the Root trait, src/traits.rs:72-94; src/impl_r_check.rs): nroots functions g_i(t, y, y') = y[comps[i]] -
  * thresholds[i] for every system -- the form of the reference's Roberts example (g0 = y0 - 1e-4, g1 = y2 - 0.01). Call
  * before the first solve; idaens_solve then reports IDAENS_ROOT_RETURN with tret = the root, yy/yp = the solution there,

@@ -332,7 +332,7 @@ __global__ void round_newton_ctl_kernel(RoundArgs a, int phase) {
             if (go) {
                 s.curiter = 0;
                 a.skipI[b] = 0;
-                a.scale[b] = idactl::after_lsolve(s, 0 /* LSolverType::Direct */, 0, false) ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:387-418
+                a.scale[b] = idactl::after_lsolve(s, IDAHIP_LS_DIRECT /* = idahip_ls_type(): the only LSolver of this library */, 0, false) ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:387-418
             }
         } else {
             a.skipS[b] = 1;

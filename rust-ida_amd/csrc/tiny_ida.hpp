@@ -237,7 +237,7 @@ struct TinyNewton {
         double vv[TINY_N];
         for (int i = 0; i < n; ++i) vv[i] = -a.v.delta[vb + i];
         tiny_getrs(a.lu + lub, n, a.piv + vb, vv);
-        const double sc = idactl::after_lsolve(s, 0 /* LSolverType::Direct */, 0, false) ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:387-418
+        const double sc = idactl::after_lsolve(s, IDAHIP_LS_DIRECT /* = idahip_ls_type(): the only LSolver of this library */, 0, false) ? 2.0 / (1.0 + s.cjratio) : 1.0;  // ida_ls.rs:387-418
         double acc = 0.0;
         for (int i = 0; i < n; ++i) {
             const double d = vv[i] * sc;

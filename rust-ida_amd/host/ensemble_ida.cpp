@@ -36,6 +36,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -456,6 +457,10 @@ int newton_solve_batched(idaens* e, const std::vector<int32_t>& act) {
             // scaled by 2 / (1 + cjratio) (:405-410). The library's solver is Direct with no iterations and no failures.
             const int lst = idahip_ls_type(e->ctx);
             const long nli_inc = idahip_ls_num_iters(e->ctx);
+            // tol = sqrt(N) * eplifac for an iterative solver, 0 for a direct one (:323-329; eplifac = 0.05, :211). The fused
+            // iteration kernel is LSolver::solve of the DIRECT solver and takes no tolerance: anything else has no kernel here.
+            const double tol = lsolve_tol(lst, std::sqrt((double)e->n), EPLIFAC);
+            if (lst != IDAHIP_LS_DIRECT || tol != 0.0) return efail(e, -3, "LSolverType %d (tol %g): only the dense direct solver is implemented", lst, tol);
             for (int b : I) sc.push_back(after_lsolve(S[b], lst, nli_inc, false) ? 2.0 / (1.0 + S[b].cjratio) : 1.0);
         }
         C.clear();
@@ -750,28 +755,43 @@ int idaens_create(idaens** out, idahip_ctx* ctx, const double* hYY0, const doubl
     // (tests/test_glibc_pow.py); on another libm they need not, and the two steppers would then take different step
     // sequences without a sign. Checked once per process on the controller's argument ranges: on a mismatch the ensemble
     // stays on the host stepper and says so in its error text.
-    static int g_pow_ok = -1;
-    if (g_pow_ok < 0) {
-        std::vector<double> x, y, r;
-        unsigned long long z = 0x9E3779B97F4A7C15ull;
-        auto u01 = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (double)(z >> 11) / 9007199254740992.0; };
-        for (int i = 0; i < 384; ++i) {
-            const int k = 1 + i % 6;
-            x.push_back(1.0e-4 + 3.0 * u01());                      // 2 err + 0.0001 (handle_n_flag, complete_step), delnrm / oldnrm (ctest)
-            y.push_back((i & 1) ? -1.0 / (double)(k + 1) : 1.0 / (double)k);
-        }
-        r.resize(x.size());
-        g_pow_ok = 1;
-        if (idahip_pow_batch(ctx, x.data(), y.data(), r.data(), x.size()) != 0) {
-            g_pow_ok = 0;
-        } else {
-            for (size_t i = 0; i < x.size(); ++i) {
-                const double h = std::pow(x[i], y[i]);
-                if (std::memcmp(&h, &r[i], sizeof h) != 0) g_pow_ok = 0;
+    // (the verdict is process-wide and guarded: ensembles may be created from several host threads. A self-check that could not
+    // RUN -- idahip_pow_batch failed -- is not a verdict: this ensemble stays on the host stepper, says why, and the next
+    // idaens_create tries again.)
+    static std::mutex g_pow_mu;
+    static int g_pow_ok = -1;  // -1: not known yet, 0: bits differ, 1: bit-identical
+    bool could_not_run = false;
+    int pow_ok;
+    {
+        std::lock_guard<std::mutex> lk(g_pow_mu);
+        if (g_pow_ok < 0) {
+            std::vector<double> x, y, r;
+            unsigned long long z = 0x9E3779B97F4A7C15ull;
+            auto u01 = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (double)(z >> 11) / 9007199254740992.0; };
+            for (int i = 0; i < 384; ++i) {
+                const int k = 1 + i % 6;
+                x.push_back(1.0e-4 + 3.0 * u01());                      // 2 err + 0.0001 (handle_n_flag, complete_step), delnrm / oldnrm (ctest)
+                y.push_back((i & 1) ? -1.0 / (double)(k + 1) : 1.0 / (double)k);
+            }
+            r.resize(x.size());
+            if (idahip_pow_batch(ctx, x.data(), y.data(), r.data(), x.size()) != 0) {
+                could_not_run = true;
+            } else {
+                g_pow_ok = 1;
+                for (size_t i = 0; i < x.size(); ++i) {
+                    const double h = std::pow(x[i], y[i]);
+                    if (std::memcmp(&h, &r[i], sizeof h) != 0) g_pow_ok = 0;
+                }
             }
         }
+        pow_ok = g_pow_ok;
     }
-    if (!g_pow_ok) {
+    if (could_not_run) {
+        e->device_ctl = false;
+        e->pow_mismatch = true;
+        e->err = std::string("the device pow self-check could not run (idahip_pow_batch failed: ") + idahip_last_error(ctx) +
+                 "): the device steppers are off for this ensemble (host stepper in use)";
+    } else if (pow_ok == 0) {
         e->device_ctl = false;
         e->pow_mismatch = true;
         e->err = "the device pow does not reproduce this host's std::pow bit for bit: the device steppers are off (host stepper in use)";
@@ -1199,6 +1219,13 @@ int solve_core(idaens* e, SolveCall& C, double* hTret, int32_t* hStatus, long ma
 }  // namespace
 
 extern "C" {
+
+int idaens_device_controller_active(const idaens* e) {
+    if (!e) return -1;
+    SolveCall C;
+    C.itask = IDAENS_NORMAL;
+    return device_ctl_applies(e, C);
+}
 
 int idaens_solve(idaens* e, double tout, int itask, double* hTret, int32_t* hStatus, long max_rounds) {
     if (!e || !hTret || !hStatus) return -1;

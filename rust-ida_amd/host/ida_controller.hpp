@@ -187,6 +187,7 @@ IDA_HD inline void after_lsetup(SysCore& s, int info) {
 // ---------------------------------------------------------------- idaLsSolve's bookkeeping around LSolver::solve (ida_ls.rs:316-418)
 // ls_type: LSolverType (0 Direct, 1 Iterative, 2 MatrixIterative; include/ida_hip.h). Returns the tolerance the solver is to be
 // called with: sqrt(N) * eplifac for an iterative solver, 0 for a direct one (:323-329).
+constexpr double EPLIFAC = 0.05;  // ida_ls.rs:211 (pt05)
 IDA_HD inline double lsolve_tol(int ls_type, double sqrt_n, double eplifac) { return ls_type == 0 ? 0.0 : sqrt_n * eplifac; }
 // after the solve: nli += num_iters for an iterative solver (:389-400), ncfl += 1 when the solver failed (:413-415); returns
 // whether the correction is to be scaled by 2 / (1 + cjratio) -- direct and matrix-iterative solvers only (:405-410)

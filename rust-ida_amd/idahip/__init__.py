@@ -40,7 +40,7 @@ HIP_SYMBOLS = [
     "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build",
 ]
 ENS_SYMBOLS = [
-    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_set_roots", "idaens_set_root_fn",
+    "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
     "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
@@ -129,6 +129,7 @@ def load():
     E.idaens_set_max_ord.argtypes = [vp, ci]
     E.idaens_set_fused_newton.argtypes = [vp, ci]
     E.idaens_set_device_controller.argtypes = [vp, ci]
+    E.idaens_device_controller_active.argtypes = [vp]
     E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
     E.idaens_set_root_fn.argtypes = [vp, ci, ROOT_FN, vp]
     E.idaens_get_roots.argtypes = [vp, i32p]
@@ -483,7 +484,13 @@ class Ensemble:
 
     def set_device_controller(self, on):
         """Small device problems: the whole of Ida::solve in one launch (default on) or the lock-step host stepper."""
-        self.E.idaens_set_device_controller(self.h, int(on))
+        rc = self.E.idaens_set_device_controller(self.h, int(on))
+        if rc != 0:  # refused: the device pow does not have this host's bits, or its self-check could not run
+            raise IdaHipError("set_device_controller(%d) refused (%d): %s" % (int(on), rc, self.E.idaens_last_error(self.h).decode()))
+
+    def device_controller_active(self):
+        """0 = host stepper, 1 = device stepper with one thread per system, 2 = device lock-step rounds (what a NORMAL solve would use)."""
+        return int(self.E.idaens_device_controller_active(self.h))
 
     def set_max_ord(self, maxord):
         if self.E.idaens_set_max_ord(self.h, int(maxord)) != 0:

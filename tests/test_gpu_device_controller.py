@@ -15,7 +15,9 @@ def make(prob, device_ctl):
     from idahip import problems
     ctx = problems.make_ctx(prob)
     ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
-    ens.set_device_controller(device_ctl)
+    ens.set_device_controller(device_ctl)  # (raises if the library refuses: device pow != host pow)
+    # the stepper that will really run: a 'device == host stepper' comparison must not silently compare host with host
+    assert (ens.device_controller_active() != 0) == bool(device_ctl), ens.device_controller_active()
     return ctx, ens
 
 
@@ -187,26 +189,58 @@ def test_switching_steppers_between_round_limited_calls(n, batch):
     """A round-limited call of the device lock-step stepper can leave a system INSIDE an attempt whose Newton solve has to
     start over with a linear setup in the next round (newton_retry, round_ida.hpp). The next call may run on the host stepper
     (idaens_set_device_controller(0), roots, tracing ...): it must continue that attempt -- not begin it again. One round per
-    call, the stepper alternating from call to call, against both steppers run alone."""
+    call, the stepper alternating from call to call, against the device stepper run alone.
+    A linear problem never takes that path by itself (a stale Jacobian contracts at |1 - cjratio| / (1 + cjratio) <= 0.25), so
+    the test makes the Jacobians stale the hard way: after six rounds the user replaces A by 3 A (idahip_set_linear_dense
+    between two solve calls). Every system whose next Newton solve starts on its old factors then diverges (rate > 0.9,
+    ConvergenceRecover with jcur == false) -- in a device round, since the seventh call is one -- and starts over in the call after
+    it, which runs on the host stepper."""
     from idahip import problems
     prob = problems.linear_dense(n=n, batch=batch, procs=1)
     touts = prob["touts"]
+    R0 = 6
+
+    def swap(ctx):
+        ctx.set_linear_dense(3.0 * prob["A"], prob["B"], prob["c"])
+
     cd, dev = make(prob, 1)
-    sd, td, rd, yd, ypd = dev.solve_schedule(touts, outputs=True)
-    assert (sd == 0).all()
+    yd = np.full((len(touts), batch, n), np.nan)
+    s, t, r, yo, ypo = dev.solve_schedule(touts, max_rounds=R0, outputs=True)
+    assert (s == 99).all(), "six rounds do not finish the schedule"
+    m = ~np.isnan(yo)
+    yd[m] = yo[m]
+    assert int(dev.counter("nls_nconvfails").sum()) == 0
+    swap(cd)
+    for _ in range(4000):
+        s, t, r, yo, ypo = dev.solve_schedule(touts, max_rounds=50, outputs=True)
+        m = ~np.isnan(yo)
+        yd[m] = yo[m]
+        if (s != 99).all():
+            break
+    assert (s == 0).all()
+    assert int(dev.counter("nls_nconvfails").sum()) > 0, "no Newton solve started over: the path under test was not taken"
+
     cm, mix = make(prob, 1)
     ym = np.full_like(yd, np.nan)
-    for i in range(4000):
-        mix.set_device_controller(1 if i % 2 == 0 else 0)
+    handed_over = 0
+    for i in range(8000):
+        if i == R0:
+            swap(cm)
+        on_device = i % 2 == 0
+        mix.set_device_controller(1 if on_device else 0)
+        assert mix.device_controller_active() == (2 if on_device else 0)
+        before = int(mix.counter("nls_nconvfails").sum())
         s, t, r, yo, ypo = mix.solve_schedule(touts, max_rounds=1, outputs=True)
+        # a ConvergenceRecover on stale factors inside a DEVICE round is served in the next round, i.e. by the next call: host stepper
+        if on_device and int(mix.counter("nls_nconvfails").sum()) > before:
+            handed_over += 1
         m = ~np.isnan(yo)
         ym[m] = yo[m]
         if (s != 99).all():
             break
     assert (s == 0).all() and np.array_equal(ym, yd)
     same(state(mix), state(dev))
-    # the path is only exercised if some Newton solve did start over: say so in the test's output
-    print("Newton-internal re-setups in this run:", int(dev.counter("nls_nconvfails").sum()))
+    assert handed_over > 0, "no one-round device call ended with a system waiting to start its Newton solve over"
 
 
 @pytest.mark.parametrize("n,batch,ntout", [(40, 6, 10), (700, 3, 3), (1100, 3, 2), (4096, 4, 2)])
@@ -275,6 +309,8 @@ def test_root_finding_on_the_device_steppers(name):
     ch, host = make(prob, 0)
     rd = _run_with_roots(dev, touts, comps, thr)
     rh = _run_with_roots(host, touts, comps, thr)
+    # with the roots set, the device ensemble still runs on its device stepper (the bracketing of ida_flow.hpp, not the host's)
+    assert dev.device_controller_active() == (1 if name == "roberts" else 2) and host.device_controller_active() == 0
     assert len(rd) == len(rh) and any((r[0] == 2).any() for r in rh), "no root return in this run"
     for a, b in zip(rd, rh):
         for x, y in zip(a, b):

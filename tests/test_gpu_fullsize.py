@@ -201,6 +201,41 @@ def test_config2_lorenz63_full_batch():
     ens.close()
 
 
+@pytest.mark.parametrize("device_ctl", [1, 0])
+def test_config2_lorenz63_whole_horizon(device_ctl):
+    """Config 2 exactly as BASELINE.json states it -- Lorenz63, N = 3, B = 1024 -- over its WHOLE horizon: all 50 outputs
+    t = 0.1 .. 5.0 against the oracle, y and y' at every output and every counter, step size and order at the end. The system
+    is chaotic: a one-ulp slip anywhere in the first outputs is a visibly different trajectory at t = 5 (and different step
+    counts well before). Device stepper (one thread per system) and host stepper."""
+    import idahip
+    from idahip import problems
+    p = problems.lorenz63(batch=1024)
+    touts = p["touts"]
+    assert len(touts) == 50 and abs(float(touts[-1]) - 5.0) < 1e-12
+    ctx = problems.make_ctx(p)
+    ens = idahip.Ensemble(ctx, p["yy0"], p["yp0"])
+    ens.set_device_controller(device_ctl)
+    assert ens.device_controller_active() == (1 if device_ctl else 0)
+    status, tret, reached, yo, ypo = ens.solve_schedule(touts, outputs=True)
+    assert (status == 0).all() and (reached == 50).all() and np.array_equal(tret, np.full(1024, touts[-1]))
+    ref = O.run_ensemble("lorenz63", 3, p["yy0"], p["yp0"], p["rtol"], p["atol"], touts, params=p["params"],
+                         nthreads=min(64, os.cpu_count() or 1))
+    assert (ref["status"] == 0).all()
+    for i in range(50):
+        assert np.array_equal(yo[i], ref["yy"][i]) and np.array_equal(ypo[i], ref["yp"][i]), "output %d (t = %g)" % (i, touts[i])
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(c["kused"], ref["kused"]) and np.array_equal(ens.real("hused"), ref["hused"])
+    assert np.array_equal(ens.yy(), ref["yy"][-1]) and np.array_equal(ens.yp(), ref["yp"][-1])
+    # trajectories really diverge over this horizon: the batch's 1e-3 spread of initial states is O(10) apart at t = 5
+    assert np.ptp(yo[-1][:, 0]) > 1.0
+    for k in QUIRK_PATHS:
+        assert int(c[k].sum()) == 0, k
+    ens.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("n,batch,ntout", [(1024, 4, 2), (4096, 256, 1)])
 def test_config4_heat1d(n, batch, ntout):
     """Config 4 (method-of-lines heat equation, tridiagonal Jacobian: the a_kj == 0 paths of the LU everywhere) at

@@ -46,25 +46,30 @@ def main():
         i0 = one.iters(); t0 = time.perf_counter(); one.run(K); dt = time.perf_counter() - t0
         print("one ensemble of %d: %d rounds %.1f ms/round, %.1f k iters/s" % (B, K, dt / K * 1e3, (one.iters() - i0) / dt / 1e3), flush=True)
     one.ens.close(); one.ctx.close(); del one
-    halves = [Half(n, B // 2, 0, stagger, mkstream()), Half(n, B // 2, B // 2, stagger, mkstream())]
-    for h in halves:  # each half alone
+    for G in [int(x) for x in os.environ.get("GROUPS", "2,3,4").split(",")]:
+        per = B // G
+        groups = [Half(n, per, g * per, stagger, mkstream()) for g in range(G)]
+        h = groups[0]
         i0 = h.iters(); t0 = time.perf_counter(); h.run(K); dt = time.perf_counter() - t0
-        print("half of %d alone: %.1f ms/round, %.1f k iters/s" % (B // 2, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
-    for delay_ms in (0.0, 4.0, 8.0):
-        for rep in range(2):
-            i0 = sum(h.iters() for h in halves)
+        print("one group of %d alone: %.1f ms/round, %.1f k iters/s" % (per, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
+        for delay_ms in ((0.0, 4.0, 8.0) if G == 2 else (0.0, 3.0)):
+            for rep in range(2):
+                i0 = sum(h.iters() for h in groups)
 
-            def go(h, d):
-                if d > 0:
-                    time.sleep(d * 1e-3)
-                h.run(K)
-            th = [threading.Thread(target=go, args=(halves[0], 0.0)), threading.Thread(target=go, args=(halves[1], delay_ms))]
-            t0 = time.perf_counter()
-            for t in th: t.start()
-            for t in th: t.join()
-            dt = time.perf_counter() - t0
-            print("two halves on two streams, second %.0f ms late: %.1f ms per round of both, %.1f k iters/s" %
-                  (delay_ms, dt / K * 1e3, (sum(h.iters() for h in halves) - i0) / dt / 1e3), flush=True)
+                def go(h, d):
+                    if d > 0:
+                        time.sleep(d * 1e-3)
+                    h.run(K)
+                th = [threading.Thread(target=go, args=(groups[g], g * delay_ms)) for g in range(G)]
+                t0 = time.perf_counter()
+                for t in th: t.start()
+                for t in th: t.join()
+                dt = time.perf_counter() - t0
+                print("%d groups of %d on %d streams, each %.0f ms after the one before: %.1f ms per round of all, %.1f k iters/s" %
+                      (G, per, G, delay_ms, dt / K * 1e3, (sum(h.iters() for h in groups) - i0) / dt / 1e3), flush=True)
+        for h in groups:
+            h.ens.close(); h.ctx.close()
+        del groups, h
 
 
 if __name__ == "__main__":
