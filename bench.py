@@ -175,69 +175,105 @@ class Runner:
         ctx.close()
         return max(1, int(round(float(np.median(att)))))
 
-    def __init__(self, prob, device, ctx=None):
+    def __init__(self, probs, device, ctxs=None, serial=False):
+        """probs / ctxs: one problem (and device context) per group. The rank's batch is integrated as len(probs) ensembles side
+        by side on the one device, each on its own HIP stream and host thread (idaens_stream_group): one group's
+        stretches of a round that leave the chip idle are filled by the others' launches. One group = round 4's single ensemble.
+        serial: the groups take turns instead (IDAHIP_BENCH_TIME_ALL / the timer passes: a kernel's duration is then its own)."""
         import idahip
         from idahip import problems
-        self.prob = prob
-        self.stagger = self.STAGGER if self.STAGGER is not None else self.integration_length(prob, device, self.CALIBRATION_SYSTEMS)
-        self.ctx = ctx if ctx is not None else problems.make_ctx(prob, device=device)
-        self.ens = idahip.Ensemble(self.ctx, prob["yy0"], prob["yp0"])
+        self.probs = probs
+        self.prob = probs[0]
+        self.serial = serial
+        self.stagger = self.STAGGER if self.STAGGER is not None else self.integration_length(probs[0], device, self.CALIBRATION_SYSTEMS)
+        self.ctxs = ctxs if ctxs is not None else [problems.make_ctx(p, device=device) for p in probs]
+        self.enss = [idahip.Ensemble(c, p["yy0"], p["yp0"]) for c, p in zip(self.ctxs, probs)]
+        self.steppers = [e.device_controller_active() for e in self.enss]
         if TIME_ALL:
-            self.ctx.timing(2)
-            self.ctx.timing_reset()
-        self.ens.stream(prob["touts"], max(self.SPIN_UP, 3 * self.stagger), stagger_rounds=self.stagger)
+            for c in self.ctxs:
+                c.timing(2)
+                c.timing_reset()
+        self._stream(max(self.SPIN_UP, 3 * self.stagger), stagger=self.stagger)
+
+    def _stream(self, k, stagger=0, serial=None):
+        import idahip
+        if (self.serial if serial is None else serial) or len(self.enss) == 1:
+            for e in self.enss:
+                e.stream(self.prob["touts"], k, stagger_rounds=stagger)
+        else:
+            idahip.stream_group(self.enss, self.prob["touts"], k, stagger_rounds=stagger)
 
     def total_iters(self):
-        return self.ens.total_newton_iters()
+        return sum(e.total_newton_iters() for e in self.enss)
 
-    def steps(self, k):
-        """Exactly k lock-step rounds (one step attempt of every system of the batch each), in one call: the host stepper runs
-        its k rounds back to back, the device-resident stepper of the small problems runs them inside one launch."""
+    def steps(self, k, serial=None):
+        """Exactly k lock-step rounds of every group (one step attempt of every system of the batch each), in one call per group:
+        the host stepper runs its k rounds back to back, the device-resident stepper of the small problems runs them inside one
+        launch; the groups run concurrently."""
         if k <= 0:
             return
-        before = self.ens.total_rounds()
-        self.ens.stream(self.prob["touts"], k)
-        assert self.ens.total_rounds() == before + k
+        before = [e.total_rounds() for e in self.enss]
+        self._stream(k, serial=serial)
+        assert [e.total_rounds() for e in self.enss] == [b + k for b in before]
 
     def sync(self):
-        self.ctx._chk(self.ctx.H.idahip_sync(self.ctx.h), "sync")
+        for c in self.ctxs:
+            c._chk(c.H.idahip_sync(c.h), "sync")
+
+    def _timing_sum(self):
+        tims = [c.timing_get() for c in self.ctxs]
+        return {k: {f: sum(t[k][f] for t in tims) for f in ("ms", "launches", "systems")} for k in tims[0]}
 
     def timed_steps(self, k, level):
-        """k more rounds with the HIP-event timers at `level` (1: per kernel class, 2: per kernel of the LU)."""
+        """k more rounds with the HIP-event timers at `level` (1: per kernel class, 2: per kernel of the LU). The groups take
+        turns here: with two streams' kernels sharing the chip a kernel's event-to-event time is no longer its own."""
         if not TIME_ALL:
-            self.ctx.timing(level)
-            self.ctx.timing_reset()
-        self.steps(k)
+            for c in self.ctxs:
+                c.timing(level)
+                c.timing_reset()
+        self.steps(k, serial=True)
         self.sync()
-        tim = self.ctx.timing_get()
+        tim = self._timing_sum()
         if not TIME_ALL:
-            self.ctx.timing(0)
+            for c in self.ctxs:
+                c.timing(0)
         return tim
 
     def whole_pass(self, variant=4, level=0, fused=1, device_ctl=1):
-        """SURVEY 8(d): the whole ensemble from fresh state (Ida::new for every system) through its output schedule."""
+        """SURVEY 8(d): the whole ensemble from fresh state (Ida::new for every system) through its output schedule; the groups
+        side by side as in the stream (idaens_solve_schedule_group)."""
         import idahip
-        self.ctx.set_lu_variant(variant)
-        ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
-        ens.set_fused_newton(fused)
-        ens.set_device_controller(device_ctl)
-        self.ctx.timing(level)
-        self.ctx.timing_reset()
+        enss = []
+        for c, p in zip(self.ctxs, self.probs):
+            c.set_lu_variant(variant)
+            e = idahip.Ensemble(c, p["yy0"], p["yp0"])
+            e.set_fused_newton(fused)
+            e.set_device_controller(device_ctl)
+            c.timing(level)
+            c.timing_reset()
+            enss.append(e)
         self.sync()
         t0 = time.perf_counter()
-        status, _, reached = ens.solve_schedule(self.prob["touts"])
+        if self.serial or len(enss) == 1:
+            res = [e.solve_schedule(self.prob["touts"]) for e in enss]
+        else:
+            res = idahip.solve_schedule_group(enss, self.prob["touts"])
         self.sync()
         dt = time.perf_counter() - t0
-        assert (status == 0).all() and (reached == len(self.prob["touts"])).all()
-        tim = self.ctx.timing_get()
-        self.ctx.timing(0)
-        c = ens.counters()
-        out = {"seconds": dt, "iters": ens.total_newton_iters(), "rounds": ens.total_rounds(), "tim": tim,
-               "counts": np.stack([c[k] for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]), "yy": ens.yy(), "yp": ens.yp(),
-               "stepper": ens.device_controller_active(),
-               "paths": {k: int(c[k].sum()) for k in ("ncfn", "nls_nconvfails", "nlufail", "nconv_jcur", "nfail_first", "nge")}}
-        ens.close()
-        self.ctx.set_lu_variant(4)
+        for status, _, reached in res:
+            assert (status == 0).all() and (reached == len(self.prob["touts"])).all()
+        tim = self._timing_sum()
+        cs = [e.counters() for e in enss]
+        cat = lambda k: np.concatenate([c[k] for c in cs])
+        out = {"seconds": dt, "iters": sum(e.total_newton_iters() for e in enss), "rounds": max(e.total_rounds() for e in enss), "tim": tim,
+               "counts": np.stack([cat(k) for k in ("nst", "netf", "ncfn", "nni", "nsetups", "kused")]),
+               "yy": np.concatenate([e.yy() for e in enss]), "yp": np.concatenate([e.yp() for e in enss]),
+               "stepper": enss[0].device_controller_active(),
+               "paths": {k: int(cat(k).sum()) for k in ("ncfn", "nls_nconvfails", "nlufail", "nconv_jcur", "nfail_first", "nge")}}
+        for e, c in zip(enss, self.ctxs):
+            e.close()
+            c.timing(0)
+            c.set_lu_variant(4)
         return out
 
 
@@ -330,6 +366,11 @@ def launch_ranks(n):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
+# ensembles per GPU by default: same-box A/Bs in DESIGN.md section 4b (tools/half_streams.py); the one-thread-per-system stepper
+# of the n = 3 problems runs whole schedules in one launch and has nothing to interleave
+DEFAULT_GROUPS = {"linear_dense": 4, "heat1d": 1, "lorenz63": 1}
+
+
 WORKLOADS = {
     "linear_dense": ("Newton iters/sec (fp64), batched dense DAE N=%d B=%d",
                      "random linear dense index-1 DAE F=A y'+B y-c (SURVEY 8(d) config 3), N=%d, B=%d systems per GPU, rtol 1e-6 "
@@ -355,6 +396,9 @@ def main():
                     help="linear_dense = config 3 (the headline, N=512 B=4096); heat1d = config 4 (N=4096 B=256); lorenz63 = config 2 (N=3 B=1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-pass figures (N = 1 extras)")
+    ap.add_argument("--groups", type=int, default=None,
+                    help="ensembles per GPU, each with 1/groups of the rank's systems on its own HIP stream and host thread "
+                         "(idaens_stream_group; default: %s)" % ", ".join("%s %d" % kv for kv in DEFAULT_GROUPS.items()))
     ap.add_argument("--passes", type=int, default=10, help="whole passes timed for `whole_pass` (SURVEY 8(d): >= 10 repetitions on fresh state, median)")
     ap.add_argument("--results-npz", default=None,
                     help="rank 0 writes the concatenated per-system results of the ensemble's verification pass (nst, nni, y(tout), y'(tout) in "
@@ -366,6 +410,8 @@ def main():
     dn, db = {"linear_dense": (512, 4096), "heat1d": (4096, 256), "lorenz63": (3, 1024)}[args.workload]
     args.n = dn if args.n is None else args.n
     args.batch = db if args.batch is None else args.batch
+    args.groups = DEFAULT_GROUPS[args.workload] if args.groups is None else args.groups
+    args.groups = max(1, min(args.groups, args.batch))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)  # does not return
@@ -387,22 +433,33 @@ def main():
         problems.ensure_fork_server()  # before anything of the GPU is loaded in this process
     t0 = time.time()
     first, count = sharding.shard_range(rank, world, args.batch)
-    stream_ctx = None
     ncpu = max(1, min(cores, 64))
     nsmall = min(args.batch, 16 * ncpu if args.workload == "linear_dense" else (ncpu if args.workload == "heat1d" else args.batch))
     if args.inputs_only:
         inputs_only(args, rank, world, first, count, procs)  # does not return
+    G = args.groups
+    gsz = [count // G + (1 if g < count % G else 0) for g in range(G)]  # the rank's systems, dealt to its groups in order
+    goff = [sum(gsz[:g]) for g in range(G)]
+    nsmall = min(nsmall, gsz[0])  # the CPU baseline's sample comes from the first group's host copy
+    stream_ctxs = None
     if args.workload == "linear_dense":
         # the shard's matrices go from the generator to the device a slice (<= 2 GiB) at a time: the process never holds the
         # 17 GB host copy of its shard (eight ranks of a node would hold 137 GB), only the calibration / CPU-baseline sample
         keep = max(Runner.CALIBRATION_SYSTEMS, nsmall if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
         rehearse_early = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
-        stream_ctx, prob = problems.make_ctx_linear_dense_streamed(args.n, count, first=first, procs=procs,
-                                                                  device=0 if rehearse_early else local_rank, keep=keep)
+        stream_ctxs, probs = [], []
+        for g in range(G):
+            c_, p_ = problems.make_ctx_linear_dense_streamed(args.n, gsz[g], first=first + goff[g], procs=procs,
+                                                             device=0 if rehearse_early else local_rank, keep=keep if g == 0 else 0)
+            stream_ctxs.append(c_)
+            probs.append(p_)
+        prob = probs[0]
     else:
         full = problems.heat1d(n=args.n, batch=args.batch * world) if args.workload == "heat1d" else problems.lorenz63(batch=args.batch * world)
-        prob = {k: (v[first:first + count] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
-                for k, v in full.items()}  # kappa_b / the initial perturbation depend on the global system id
+        cut = lambda lo, cnt: {k: (v[lo:lo + cnt] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == args.batch * world else v)
+                               for k, v in full.items()}  # kappa_b / the initial perturbation depend on the global system id
+        probs = [cut(first + goff[g], gsz[g]) for g in range(G)]
+        prob = cut(first, count)
     t_gen = time.time() - t0
 
     cpu = None
@@ -435,9 +492,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(prob, local_rank, ctx=stream_ctx)
-    prob.pop("A", None)  # host copies no longer needed
-    prob.pop("B", None)
+    run = Runner(probs, local_rank, ctxs=stream_ctxs, serial=TIME_ALL or os.environ.get("IDAHIP_BENCH_SERIAL_GROUPS") == "1")
+    for p_ in probs + [prob]:  # host copies of the matrices are no longer needed
+        p_.pop("A", None)
+        p_.pop("B", None)
 
     # ---- the number: W warm-up steps, then exactly K steps between barriers, no timers inside
     run.steps(args.warmup)
@@ -603,7 +661,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
-                       "sharding": "independent systems, contiguous block per rank, no collective"},
+                       "sharding": "independent systems, contiguous block per rank, no collective",
+                       "groups_per_gpu": args.groups, "group_sizes": gsz,
+                       "groups": "the rank's systems run as %d ensemble(s) side by side on the one device, each on its own HIP stream and host "
+                                 "thread (idaens_stream_group): every system is integrated exactly as alone; the groups only fill each other's idle "
+                                 "stretches of a lock-step round%s" % (args.groups, " -- here they take turns (serial)" if run.serial else "")},
             "newton_iters_timed": iters_all,
             "per_rank": None if world == 1 else {"newton_iters": [p[0] for p in per_rank], "seconds": [p[1] for p in per_rank],
                                                  "input_generation_s": [sh["input_generation_s"] for sh in shards],

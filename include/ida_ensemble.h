@@ -115,6 +115,23 @@ int idaens_solve_schedule(idaens* e, const double* touts, int ntout, double* hTr
  * ensemble was created. Per-system counters restart with the system; idaens_total_newton_iters keeps the total. */
 int idaens_stream(idaens* e, const double* touts, int ntout, long max_rounds, long stagger_rounds, int64_t* passes_done);
 
+/* Several ensembles side by side on ONE device. The reference integrates one IVP per `Ida` object and
+ * nothing couples two objects (src/lib.rs:89-244); how many of them a host puts into one lock-step batch is a scheduling
+ * choice. A lock-step round of one large batch is a serial chain of launches, and in some of them most of the chip idles
+ * (the panel kernels' pivot chains, the later Newton passes that serve a few hundred systems, round begin / end). Split
+ * into `ngroups` ensembles -- each created on its OWN idahip_ctx, hence its own HIP stream -- and driven by one host
+ * thread each, one group's idle stretches are filled by the other groups' launches by the device's own scheduler: same
+ * systems, same per-system results (every system is integrated exactly as alone), more of them per second.
+ * idaens_stream_group = idaens_stream for every ens[g], concurrently; group g starts g * offset_us microseconds after
+ * group 0 (0 = together). passes_done: [ngroups] or null. idaens_solve_schedule_group = idaens_solve_schedule for every
+ * ens[g], concurrently (arrays of per-group result pointers: hTret[g], hStatus[g] of length batch(ens[g]); hReached may be
+ * null). Returns 0, or the first failing group's (negative) code -- that group's idaens_last_error has the text.
+ * Host threads: the calling thread drives group 0, ngroups - 1 std::threads the others; a ctx is used by one thread only. */
+int idaens_stream_group(idaens* const* ens, int ngroups, const double* touts, int ntout, long max_rounds, long stagger_rounds, long offset_us,
+                        int64_t* passes_done);
+int idaens_solve_schedule_group(idaens* const* ens, int ngroups, const double* touts, int ntout, double* const* hTret, int32_t* const* hStatus,
+                                int32_t* const* hReached, long max_rounds);
+
 /* getters (src/ida_io.rs:11-117), arrays of length batch */
 enum {
     IDAENS_C_NST = 0, IDAENS_C_NRE = 1, IDAENS_C_NJE = 2, IDAENS_C_NSETUPS = 3, IDAENS_C_NNI = 4, IDAENS_C_NETF = 5,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,10 @@ struct idahip_ctx {
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
+    // extra dynamic LDS per workgroup of lu_trail64w_kernel<1024> (IDAHIP_TRAIL_LDS_PAD, bytes, read at idahip_create; 0 = none):
+    // from 2.5 KB on, two of its workgroups fit a CU instead of three, which leaves a third of every SIMD's registers and
+    // 50 KB of LDS to the kernels of OTHER streams (idaens_stream_group). An occupancy knob only: results do not depend on it.
+    int trail_lds_pad = 0;
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)
@@ -103,6 +108,7 @@ struct idahip_ctx {
     // timing
     int timing = 0;  // 0 off, 1 per kernel class, 2 also per kernel of the LU
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev_cnt = nullptr;  // idahip_round_solve, n > 1024: the LU list's length has reached the host
     double k_ms[IDAHIP_K_COUNT] = {0};
     int64_t k_launches[IDAHIP_K_COUNT] = {0};
     int64_t k_systems[IDAHIP_K_COUNT] = {0};

@@ -75,6 +75,10 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
     c->npad16 = (n + 15) & ~15;
+    if (const char* pad = std::getenv("IDAHIP_TRAIL_LDS_PAD")) {  // occupancy knob of the rank-64 trailing kernel (common.hpp); results do not depend on it
+        const long v = std::strtol(pad, nullptr, 10);
+        c->trail_lds_pad = (int)(v < 0 ? 0 : (v > 8192 ? 8192 : v));
+    }
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
@@ -114,7 +118,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
         else if (hipEventCreateWithFlags(&c->slots[i].done, hipEventDisableTiming) != hipSuccess) rc = -100;
     }
     if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess ||
-                hipEventCreate(&c->ev3) != hipSuccess))
+                hipEventCreate(&c->ev3) != hipSuccess || hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming) != hipSuccess))
         rc = -100;
 
     if (rc) {
@@ -154,6 +158,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
+    if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1155,6 +1160,15 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
             else hipLaunchKernelGGL(round_begin_kernel<false>, dim3(batch), dim3(WG_NT), shm_wg, c->stream, a);
             hipLaunchKernelGGL(round_lists_kernel, dim3(1), dim3(1024), 0, c->stream, a);
         }
+        // n > 1024 (config 4): a factorisation is ~640 launches, most of them one workgroup per matrix, and a third of a small
+        // batch needs one in any round -- launches sized for the whole batch cost more than they do at n = 512 (11.4 against
+        // 12.3 k iters/s in round 4). The list's length comes back to the host (4 bytes, behind the residual kernels enqueued
+        // below: the copy's round trip is hidden) and the LU's launches are sized by it, as the host stepper's are.
+        const bool lu_cnt_on_host = n > LU_MAX_N;
+        if (lu_cnt_on_host) {
+            IDAHIP_HIP(c, hipMemcpyAsync(c->rnd_host + 2, a.lu_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            IDAHIP_HIP(c, hipEventRecord(c->ev_cnt, c->stream));
+        }
         {   // sys(y0), y <- y0 = 0 (newton.rs:73): without and with the Jacobian (J = B + cj A falls out of the same sweep)
             KTimer kt(c, IDAHIP_K_SYS, 0);
             sa.reset_ee = 1; sa.skip = a.skipP;
@@ -1174,8 +1188,16 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
             if ((rc = launch_jac(c, c->jw, a.ident, a.cj, batch, nullptr, nullptr, nullptr, a.skipL))) return rc;
         }
         {
+            int nlu = batch;
+            const int* d_cnt = a.lu_cnt;
+            if (lu_cnt_on_host) {
+                IDAHIP_HIP(c, hipEventSynchronize(c->ev_cnt));
+                nlu = c->rnd_host[2];
+                d_cnt = nullptr;
+                if (nlu < 0 || nlu > batch) return fail(c, -4, "list length %d outside 0..%d", nlu, batch);
+            }
             KTimer kt(c, IDAHIP_K_LU, 0);
-            if ((rc = lu_factor_batched(c, c->jw, nn, c->lu, nn, (long long*)c->piv, n, c->perm, a.lu_list, batch, a.lu_cnt))) return rc;
+            if ((rc = lu_factor_batched(c, c->jw, nn, c->lu, nn, (long long*)c->piv, n, c->perm, a.lu_list, nlu, d_cnt))) return rc;
             if ((rc = post_launch(c, "lu"))) return rc;
         }
         hipLaunchKernelGGL(round_newton_ctl_kernel, dim3((batch + 255) / 256), dim3(256), 0, c->stream, a, 0);

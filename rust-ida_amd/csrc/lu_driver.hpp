@@ -125,7 +125,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 hipLaunchKernelGGL(lu_u12_zero_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * (ncb + (nsplit - 1) * nbs)), dim3(256), 0, c->stream, w, k0, nsys, ncb, nsplit);
             } else
-                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, 1);
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), (size_t)c->trail_lds_pad, c->stream, w, k0, nsys, ncb, 1);
         }
     }
     {

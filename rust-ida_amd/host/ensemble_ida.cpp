@@ -36,8 +36,11 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <chrono>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ida_ensemble.h"
@@ -1271,6 +1274,60 @@ int idaens_solve_schedule(idaens* e, const double* touts, int ntout, double* hTr
     C.hYout = hYout;
     C.hYPout = hYPout;
     return solve_core(e, C, hTret, hStatus, max_rounds);
+}
+
+// ---- several ensembles side by side on one device (include/ida_ensemble.h): one host thread per ensemble, each on its own
+// context and HIP stream. The ensembles share nothing; what they gain is the device's own scheduling -- while one group's
+// round is in a part that leaves most of the chip idle (the serial chain of the panel kernels, the later Newton passes and
+// their residuals for a few hundred systems, round begin / end), the other groups' launches fill it.
+namespace {
+int check_group(idaens* const* ens, int ngroups) {
+    if (!ens || ngroups < 1) return -1;
+    for (int g = 0; g < ngroups; ++g)
+        if (!ens[g]) return -1;
+    for (int g = 0; g < ngroups; ++g)
+        for (int h = g + 1; h < ngroups; ++h)
+            if (ens[g] == ens[h] || ens[g]->ctx == ens[h]->ctx)
+                return efail(ens[0], -2, "the ensembles of a group need a context (and HIP stream) each: groups %d and %d share one", g, h);
+    return 0;
+}
+int run_group(int ngroups, long offset_us, const std::function<int(int)>& one) {
+    std::vector<int> rc(ngroups, 0);
+    std::vector<std::thread> th;
+    th.reserve(ngroups > 0 ? ngroups - 1 : 0);
+    for (int g = 1; g < ngroups; ++g)
+        th.emplace_back([&, g]() {
+            if (offset_us > 0) std::this_thread::sleep_for(std::chrono::microseconds((long long)g * offset_us));
+            rc[g] = one(g);
+        });
+    rc[0] = one(0);  // group 0 on the calling thread
+    for (auto& t : th) t.join();
+    int worst = 0;
+    for (int g = 0; g < ngroups; ++g)
+        if (rc[g] < worst || (worst == 0 && rc[g] != 0)) worst = rc[g];
+    return worst;
+}
+}  // namespace
+
+int idaens_stream_group(idaens* const* ens, int ngroups, const double* touts, int ntout, long max_rounds, long stagger_rounds, long offset_us,
+                        int64_t* passes_done) {
+    const int rc = check_group(ens, ngroups);
+    if (rc) return rc;
+    return run_group(ngroups, offset_us, [&](int g) {
+        return idaens_stream(ens[g], touts, ntout, max_rounds, stagger_rounds, passes_done ? passes_done + g : nullptr);
+    });
+}
+
+int idaens_solve_schedule_group(idaens* const* ens, int ngroups, const double* touts, int ntout, double* const* hTret, int32_t* const* hStatus,
+                                int32_t* const* hReached, long max_rounds) {
+    const int rc = check_group(ens, ngroups);
+    if (rc) return rc;
+    if (!hTret || !hStatus) return -1;
+    for (int g = 0; g < ngroups; ++g)
+        if (!hTret[g] || !hStatus[g]) return -1;
+    return run_group(ngroups, 0, [&](int g) {
+        return idaens_solve_schedule(ens[g], touts, ntout, hTret[g], hStatus[g], hReached ? hReached[g] : nullptr, nullptr, nullptr, max_rounds);
+    });
 }
 
 namespace {

@@ -41,7 +41,7 @@ HIP_SYMBOLS = [
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
-    "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream",
+    "idaens_get_roots", "idaens_solve", "idaens_solve_schedule", "idaens_stream", "idaens_stream_group", "idaens_solve_schedule_group",
     "idaens_get_counter", "idaens_get_real", "idaens_get_yy", "idaens_get_yp", "idaens_get_dky", "idaens_total_newton_iters",
     "idaens_total_rounds", "idaens_trace_system", "idaens_trace_len", "idaens_trace_get",
 ]
@@ -130,6 +130,8 @@ def load():
     E.idaens_set_fused_newton.argtypes = [vp, ci]
     E.idaens_set_device_controller.argtypes = [vp, ci]
     E.idaens_device_controller_active.argtypes = [vp]
+    E.idaens_stream_group.argtypes = [C.POINTER(vp), ci, dp, ci, C.c_long, C.c_long, C.c_long, i64p]
+    E.idaens_solve_schedule_group.argtypes = [C.POINTER(vp), ci, dp, ci, C.POINTER(dp), C.POINTER(i32p), C.POINTER(i32p), C.c_long]
     E.idaens_set_roots.argtypes = [vp, ci, i32p, dp]
     E.idaens_set_root_fn.argtypes = [vp, ci, ROOT_FN, vp]
     E.idaens_get_roots.argtypes = [vp, i32p]
@@ -578,3 +580,41 @@ class Ensemble:
         if k:
             self.E.idaens_trace_get(self.h, _p(out))
         return out
+
+
+def _group_handles(ensembles):
+    arr = (C.c_void_p * len(ensembles))(*[e.h for e in ensembles])
+    return arr
+
+
+def stream_group(ensembles, touts, max_rounds, stagger_rounds=0, offset_us=0):
+    """idaens_stream_group: Ensemble.stream for every ensemble of the group at once (one host thread and one HIP stream per
+    ensemble, all on one device; group g starts g * offset_us microseconds after group 0). -> integrations completed, per group."""
+    touts = _f64(np.atleast_1d(touts))
+    E = ensembles[0].E
+    done = np.zeros(len(ensembles), dtype=np.int64)
+    rc = E.idaens_stream_group(_group_handles(ensembles), len(ensembles), _p(touts), touts.size, int(max_rounds), int(stagger_rounds),
+                               int(offset_us), _p(done, i64p))
+    if rc < 0:
+        texts = [(e.E.idaens_last_error(e.h) or b"").decode() for e in ensembles]
+        raise IdaHipError("idaens_stream_group failed (%d): %s" % (rc, " | ".join(t for t in texts if t)))
+    return done
+
+
+def solve_schedule_group(ensembles, touts, max_rounds=0):
+    """idaens_solve_schedule_group: Ensemble.solve_schedule for every ensemble of the group at once.
+    -> [(status, tret, reached)] per group."""
+    touts = _f64(np.atleast_1d(touts))
+    E = ensembles[0].E
+    G = len(ensembles)
+    tret = [np.zeros(e.ctx.batch) for e in ensembles]
+    status = [np.zeros(e.ctx.batch, dtype=np.int32) for e in ensembles]
+    reached = [np.zeros(e.ctx.batch, dtype=np.int32) for e in ensembles]
+    pt = (dp * G)(*[_p(a) for a in tret])
+    ps = (i32p * G)(*[_p(a, i32p) for a in status])
+    pr = (i32p * G)(*[_p(a, i32p) for a in reached])
+    rc = E.idaens_solve_schedule_group(_group_handles(ensembles), G, _p(touts), touts.size, pt, ps, pr, int(max_rounds))
+    if rc < 0:
+        texts = [(e.E.idaens_last_error(e.h) or b"").decode() for e in ensembles]
+        raise IdaHipError("idaens_solve_schedule_group failed (%d): %s" % (rc, " | ".join(t for t in texts if t)))
+    return list(zip(status, tret, reached))

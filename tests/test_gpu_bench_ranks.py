@@ -29,7 +29,7 @@ def test_bench_ranks_rehearsal(ranks, tmp_path):
     assert pr["process_group"].startswith("gloo")
     # run hygiene of an N-rank line: every rank says how long its inputs took and which device it ran on
     assert len(pr["input_generation_s"]) == ranks and len(pr["devices"]) == ranks
-    assert all(d["local_rank"] == 0 and d["name"] for d in pr["devices"])  # (the rehearsal puts every rank on cuda:0, and says so)
+    assert all(d["local_rank"] == 0 and "name" in d and d["total_memory_GiB"] > 0 for d in pr["devices"]), pr["devices"]  # (the rehearsal puts every rank on cuda:0, and says so)
     assert "rehearsal" in line and pr["generator_processes"] == 1
 
     # ---- results, not contract fields ("host concatenates"): the ranks' blocks, concatenated in rank order, are

@@ -20,9 +20,14 @@ def mkstream():
     return s
 
 
+FULL = None  # the B systems, generated once; every configuration slices them
+
+
 class Half:
     def __init__(self, n, batch, first, stagger, stream):
-        self.ctx, self.prob = problems.make_ctx_linear_dense_streamed(n, batch, first=first, procs=PROCS, stream=stream)
+        self.prob = {k: (v[first:first + batch] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == FULL["yy0"].shape[0] and k not in ("atol", "touts") else v)
+                     for k, v in FULL.items()}
+        self.ctx = problems.make_ctx(self.prob, stream=stream)
         self.ens = idahip.Ensemble(self.ctx, self.prob["yy0"], self.prob["yp0"])
         self.ens.stream(self.prob["touts"], max(200, 3 * stagger), stagger_rounds=stagger)
 
@@ -39,33 +44,32 @@ def main():
     n, stagger = 512, 62
     if PROCS > 1:
         problems.ensure_fork_server()  # before anything touches the GPU
+    global FULL
+    FULL = problems.linear_dense(n=n, batch=B, procs=PROCS)
     hip.hipInit(0)
     hip.hipSetDevice(0)
     one = Half(n, B, 0, stagger, mkstream())
-    for rep in range(3):
+    for rep in range(int(os.environ.get("ONE_REPS", "3"))):
         i0 = one.iters(); t0 = time.perf_counter(); one.run(K); dt = time.perf_counter() - t0
         print("one ensemble of %d: %d rounds %.1f ms/round, %.1f k iters/s" % (B, K, dt / K * 1e3, (one.iters() - i0) / dt / 1e3), flush=True)
     one.ens.close(); one.ctx.close(); del one
-    for G in [int(x) for x in os.environ.get("GROUPS", "2,3,4").split(",")]:
+    # configurations "groups[:pad]" in the order given (a configuration may appear twice: run-to-run spread on one box)
+    for cfg in os.environ.get("NGROUPS", "2,3,4").split(","):
+        G, pad = (int(x) for x in (cfg.split(":") + ["0"])[:2])
+        os.environ["IDAHIP_TRAIL_LDS_PAD"] = str(pad)  # read by idahip_create: occupancy knob of the trailing kernel
         per = B // G
         groups = [Half(n, per, g * per, stagger, mkstream()) for g in range(G)]
+        print("---- %d groups, trailing-kernel LDS pad %d" % (G, pad), flush=True)
         h = groups[0]
         i0 = h.iters(); t0 = time.perf_counter(); h.run(K); dt = time.perf_counter() - t0
         print("one group of %d alone: %.1f ms/round, %.1f k iters/s" % (per, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
-        for delay_ms in ((0.0, 4.0, 8.0) if G == 2 else (0.0, 3.0)):
-            for rep in range(2):
+        for delay_ms in (0.0,):
+            for rep in range(3):
                 i0 = sum(h.iters() for h in groups)
-
-                def go(h, d):
-                    if d > 0:
-                        time.sleep(d * 1e-3)
-                    h.run(K)
-                th = [threading.Thread(target=go, args=(groups[g], g * delay_ms)) for g in range(G)]
                 t0 = time.perf_counter()
-                for t in th: t.start()
-                for t in th: t.join()
+                idahip.stream_group([h.ens for h in groups], groups[0].prob["touts"], K, offset_us=int(delay_ms * 1000))  # the product's entry point
                 dt = time.perf_counter() - t0
-                print("%d groups of %d on %d streams, each %.0f ms after the one before: %.1f ms per round of all, %.1f k iters/s" %
+                print("%d groups of %d on %d streams (idaens_stream_group), each %.0f ms after the one before: %.1f ms per round of all, %.1f k iters/s" %
                       (G, per, G, delay_ms, dt / K * 1e3, (sum(h.iters() for h in groups) - i0) / dt / 1e3), flush=True)
         for h in groups:
             h.ens.close(); h.ctx.close()

@@ -62,10 +62,41 @@ _bench = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_bench)
 b = json.loads(open(bench).read().strip().splitlines()[-1])
 lu_mats = b["kernel_classes_rank0"]["lu"]["systems"]
+# traffic against the algorithmic bytes, per kernel, COMPUTED here (not transcribed into a document): the byte counts are
+# bench.py's, the systems / matrices served are the ones the bench line of the profiled run reports. The trace
+# also holds the launches of the stagger calibration (128 systems of the first group), which the bench line's class counters do
+# not: the ratio of a kernel is therefore high by the share of those launches (about 1 % in the default run).
+_n = b.get("config", {}).get("n", 512)
+_ab = _bench.algorithmic_bytes(_n, "linear_dense")
+_cls = b["kernel_classes_rank0"]
+_alg = {}
+for name in k:
+    if name.startswith("newton_iter_kernel"):
+        _alg[name] = _ab["newton_iter"] * _cls["newton_iter"]["systems"]
+    elif name.startswith("linear_sys_kernel") and "true" in name:
+        _alg[name] = _ab["sys_jac"] * _cls["sys_jac"]["systems"]
+    elif name.startswith("linear_sys_kernel"):
+        _alg[name] = _ab["sys"] * _cls["sys"]["systems"]
+    elif name.startswith("lu_trail64w_kernel"):
+        _alg[name] = _bench.trailing_work(_n)[1] * lu_mats
+    elif name.startswith("lu_finalize_kernel"):
+        _alg[name] = 16.0 * _n * _n * lu_mats  # the matrix read and written once (U rows right of their panel are already in place: a little less)
+_wp = [name for name in k if name.startswith("lu_wavepanel_kernel") and "hbm_read_GB_total" in k[name]]
+for name, d in k.items():
+    if name in _alg and "hbm_read_GB_total" in d and _alg[name] > 0:
+        d["algorithmic_GB_total"] = round(_alg[name] / 1e9, 3)
+        d["traffic_over_algorithmic"] = round((d["hbm_read_GB_total"] + d["hbm_write_GB_total"]) * 1e9 / _alg[name], 3)
+_panels = None
+if _wp:
+    _palg = sum(16.0 * (_n - k0) * min(64, _n - k0) for k0 in range(0, _n, 64)) * lu_mats  # every super-panel read and written once
+    _pt = sum(k[name]["hbm_read_GB_total"] + k[name]["hbm_write_GB_total"] for name in _wp) * 1e9
+    _panels = {"algorithmic_GB_total": round(_palg / 1e9, 3), "traffic_over_algorithmic": round(_pt / _palg, 3),
+               "total_ms": round(sum(k[name]["total_ms"] for name in _wp), 3)}
 res = {"commit": os.environ.get("GIT_COMMIT", "unknown"), "kernel_sources_sha": _bench.kernel_sources_sha(),
        "bench": {**{kk: b[kk] for kk in ("value", "steps", "warmup", "ms_per_step", "kernel_classes_rank0") if kk in b},
                  "lu_kernels_rank0": b.get("lu_kernels_rank0"), "lu_matrices": lu_mats},
        "kernels": k,
+       "lu_wavepanel_kernels_together": _panels,
        "lu_hbm_bytes_per_matrix": {name: int((d["hbm_read_GB_total"] + d["hbm_write_GB_total"]) * 1e9 / max(1, lu_mats))
                                    for name, d in k.items() if name.startswith("lu_") and "hbm_read_GB_total" in d},
        "note": "kernel stats and PMC passes are separate runs of the same command (python3 bench.py --steps 40 --warmup 0 "
