@@ -437,22 +437,28 @@ def main():
     nsmall = min(args.batch, 16 * ncpu if args.workload == "linear_dense" else (ncpu if args.workload == "heat1d" else args.batch))
     if args.inputs_only:
         inputs_only(args, rank, world, first, count, procs)  # does not return
-    G = args.groups
+    G = 1 if TIME_ALL else args.groups  # the profile runs (tools/profile_bench.sh) are about the kernels: one ensemble, one stream
+    args.groups = G
     gsz = [count // G + (1 if g < count % G else 0) for g in range(G)]  # the rank's systems, dealt to its groups in order
     goff = [sum(gsz[:g]) for g in range(G)]
     nsmall = min(nsmall, gsz[0])  # the CPU baseline's sample comes from the first group's host copy
     stream_ctxs = None
+    # one HIP stream per group, chosen so that the device runs them side by side (the runtime may put two streams on one hardware
+    # queue: idahip_concurrent_streams finds that out with a probe kernel); one group: the context's own stream
+    import idahip
+    dev_early = 0 if os.environ.get("IDAHIP_BENCH_REHEARSE") == "1" else local_rank
+    gstreams, nconc = (idahip.concurrent_streams(G, dev_early) if G > 1 else ([None], 1))
     if args.workload == "linear_dense":
         # the shard's matrices go from the generator to the device a slice (<= 2 GiB) at a time: the process never holds the
         # 17 GB host copy of its shard (eight ranks of a node would hold 137 GB), only the calibration / CPU-baseline sample
         keep = max(Runner.CALIBRATION_SYSTEMS, nsmall if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
         rehearse_early = os.environ.get("IDAHIP_BENCH_REHEARSE") == "1"
-        stream_ctxs, probs = [], []
-        for g in range(G):
-            c_, p_ = problems.make_ctx_linear_dense_streamed(args.n, gsz[g], first=first + goff[g], procs=procs,
-                                                             device=0 if rehearse_early else local_rank, keep=keep if g == 0 else 0)
-            stream_ctxs.append(c_)
-            probs.append(p_)
+        # every group's context, and (more than one group) one context with ALL of the rank's systems: the per-kernel timers
+        # run on that one, at the launch sizes the roofline figures of earlier rounds are quoted for
+        parts = [(goff[g], gsz[g], gstreams[g]) for g in range(G)] + ([(0, count, None)] if G > 1 else [])
+        made = problems.make_ctxs_linear_dense_streamed(args.n, first, count, parts, procs=procs, device=0 if rehearse_early else local_rank, keep=keep)
+        stream_ctxs, probs = [m[0] for m in made[:G]], [m[1] for m in made[:G]]
+        full_ctx, full_prob = made[G] if G > 1 else (None, None)
         prob = probs[0]
     else:
         full = problems.heat1d(n=args.n, batch=args.batch * world) if args.workload == "heat1d" else problems.lorenz63(batch=args.batch * world)
@@ -460,6 +466,7 @@ def main():
                                for k, v in full.items()}  # kappa_b / the initial perturbation depend on the global system id
         probs = [cut(first + goff[g], gsz[g]) for g in range(G)]
         prob = cut(first, count)
+        full_ctx, full_prob = None, (prob if G > 1 else None)
     t_gen = time.time() - t0
 
     cpu = None
@@ -492,7 +499,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(probs, local_rank, ctxs=stream_ctxs, serial=TIME_ALL or os.environ.get("IDAHIP_BENCH_SERIAL_GROUPS") == "1")
+    if stream_ctxs is None:
+        stream_ctxs = [problems.make_ctx(p_, device=local_rank, stream=gstreams[g]) for g, p_ in enumerate(probs)]
+    run = Runner(probs, local_rank, ctxs=stream_ctxs, serial=os.environ.get("IDAHIP_BENCH_SERIAL_GROUPS") == "1")
+    # the kernels' own figures (kernel_classes_rank0, lu_kernels_rank0, roofline, lu_plus_solve) are measured on ONE ensemble of all
+    # of the rank's systems, alone on the device, after the timed region: a kernel's event-to-event time is only its own when
+    # no other stream shares the chip, and the launch sizes are then those of a whole batch
+    Runner.STAGGER = run.stagger
+    krun = run if G == 1 else Runner([full_prob], local_rank, ctxs=[full_ctx] if full_ctx is not None else None)
     for p_ in probs + [prob]:  # host copies of the matrices are no longer needed
         p_.pop("A", None)
         p_.pop("B", None)
@@ -515,8 +529,8 @@ def main():
         dist.all_gather_object(per_rank, (int(iters), round(elapsed, 6)))
 
     # ---- untimed repetitions of the same K steps with event timers: per kernel class, then per kernel of the LU
-    tim = run.timed_steps(args.steps, 1)
-    tim2 = run.timed_steps(args.steps, 2)
+    tim = krun.timed_steps(args.steps, 1)
+    tim2 = krun.timed_steps(args.steps, 2)
     if TIME_ALL:
         tim = tim2  # the timers were never reset: both are totals over every launch of the process
 
@@ -662,7 +676,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective",
-                       "groups_per_gpu": args.groups, "group_sizes": gsz,
+                       "groups_per_gpu": args.groups, "group_sizes": gsz, "mutually_concurrent_streams": nconc,
                        "groups": "the rank's systems run as %d ensemble(s) side by side on the one device, each on its own HIP stream and host "
                                  "thread (idaens_stream_group): every system is integrated exactly as alone; the groups only fill each other's idle "
                                  "stretches of a lock-step round%s" % (args.groups, " -- here they take turns (serial)" if run.serial else "")},
@@ -682,6 +696,11 @@ def main():
             "roofline": roof,
             "kernel_classes_rank0": classes,
             "lu_kernels_rank0": lu_kernels,
+            "kernel_figures_measured_on": ("the %d groups' one ensemble" % G if G == 1 else
+                                           "ONE ensemble of all %d systems of the rank, alone on the device, after the timed region (K rounds with per-class "
+                                           "event timers, K more with per-kernel timers for the LU): kernel_classes_rank0, lu_kernels_rank0, roofline, "
+                                           "lu_plus_solve and hbm_roofline's iterations per setup are the kernels' own figures at whole-batch launch sizes; "
+                                           "`value` runs the same kernels as %d groups side by side" % (count, G)),
             "lu_plus_solve": lu_plus_solve(tim, args.n, "unfused", dense=args.workload != "heat1d") if args.n > 8 else None,
             "cpu_baseline": cpu,
             "input_generation_s": round(t_gen, 1),

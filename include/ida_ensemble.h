@@ -126,7 +126,9 @@ int idaens_stream(idaens* e, const double* touts, int ntout, long max_rounds, lo
  * group 0 (0 = together). passes_done: [ngroups] or null. idaens_solve_schedule_group = idaens_solve_schedule for every
  * ens[g], concurrently (arrays of per-group result pointers: hTret[g], hStatus[g] of length batch(ens[g]); hReached may be
  * null). Returns 0, or the first failing group's (negative) code -- that group's idaens_last_error has the text.
- * Host threads: the calling thread drives group 0, ngroups - 1 std::threads the others; a ctx is used by one thread only. */
+ * Host threads: the calling thread drives group 0, ngroups - 1 std::threads the others; a ctx is used by one thread only.
+ * Create the contexts on streams from idahip_concurrent_streams (ida_hip.h): the HIP runtime is free to put two ordinary
+ * streams on one hardware queue, and those two groups then take turns instead of running side by side. */
 int idaens_stream_group(idaens* const* ens, int ngroups, const double* touts, int ntout, long max_rounds, long stagger_rounds, long offset_us,
                         int64_t* passes_done);
 int idaens_solve_schedule_group(idaens* const* ens, int ngroups, const double* touts, int ntout, double* const* hTret, int32_t* const* hStatus,

@@ -68,6 +68,14 @@ typedef enum {
 /* ---- lifetime: LS::new(n) + NLS::new(n, maxiters) + IdaNLProblem::new (src/lib.rs:399-400, src/ida_ls.rs:192) ---- */
 int idahip_create(idahip_ctx** ctx, int device, int n, int batch, idahip_problem kind, void* hip_stream /* or NULL */);
 int idahip_destroy(idahip_ctx* ctx);
+/* `count` HIP streams on `device` for contexts that are to work SIDE BY SIDE (idaens_stream_group, ida_ensemble.h). The HIP
+ * runtime maps its streams onto a few hardware queues as it sees fit, and two streams on one queue take turns; this call
+ * creates streams and keeps those a probe kernel shows to run concurrently with every stream kept before. streams_out[count]
+ * receives hipStream_t handles for idahip_create's hip_stream argument (the caller keeps ownership: idahip_release_streams
+ * after the contexts are destroyed); *nconcurrent (optional) = how many of them, from the front, are mutually concurrent --
+ * less than count when the runtime offers fewer hardware queues (GPU_MAX_HW_QUEUES, 4 by default). */
+int idahip_concurrent_streams(int device, int count, void** streams_out, int* nconcurrent);
+int idahip_release_streams(int device, int count, void** streams);
 const char* idahip_last_error(const idahip_ctx* ctx);
 int idahip_sync(idahip_ctx* ctx);
 int idahip_n(const idahip_ctx* ctx);

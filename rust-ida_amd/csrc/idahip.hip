@@ -175,6 +175,87 @@ int idahip_sync(idahip_ctx* c) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ streams that really run side by side
+// A HIP stream is not a hardware queue: the runtime multiplexes its streams onto a few of them (four by default) and which
+// stream lands on which is its business -- the kernel trace of two builds of the same program showed three of four streams on
+// ONE queue, their launches strictly one after the other (tools/group_trace.sh). Ensembles that are meant
+// to fill each other's idle stretches (idaens_stream_group) need streams the device runs CONCURRENTLY, so this entry point
+// finds them by experiment: it creates candidate streams and lets a probe kernel (one wavefront that waits 300 us on the
+// constant 100 MHz clock and notes when it started and ended) run on the candidate and on every stream chosen so far at once;
+// the candidate is kept if its interval overlaps all of theirs. Rejected candidates stay alive until the end (a destroyed
+// stream gives its queue back and the next one would take the same) and are destroyed then.
+__global__ void stream_probe_kernel(unsigned long long* out, long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(16);  // (ends by itself: the clock runs on)
+    if (threadIdx.x == 0) {
+        out[0] = t0;
+        out[1] = wall_clock64();
+    }
+}
+
+int idahip_concurrent_streams(int device, int count, void** streams_out, int* nconcurrent) {
+    if (!streams_out || count < 1 || count > 64) return -2;
+    int ndev = 0;
+    if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return -100;
+    DevGuard dev_guard__(device);
+    if (hipSetDevice(device) != hipSuccess) return -100;
+    unsigned long long* stamps = nullptr;
+    if (hipHostMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * (size_t)(count + 1)) != hipSuccess) return -100;
+    std::vector<hipStream_t> sel, rejected;
+    int rc = 0;
+    const long long ticks = 30000;  // 300 us at 100 MHz
+    for (int attempt = 0; attempt < 6 * count + 8 && (int)sel.size() < count && !rc; ++attempt) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { rc = -100; break; }
+        if (sel.empty()) {
+            sel.push_back(s);
+            continue;
+        }
+        const int k = (int)sel.size();
+        for (int i = 0; i <= k; ++i) stamps[2 * i] = stamps[2 * i + 1] = 0ull;
+        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, sel[i], stamps + 2 * i, ticks);
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, s, stamps + 2 * k, ticks);
+        bool ok = hipGetLastError() == hipSuccess;
+        for (int i = 0; i < k; ++i) ok = (hipStreamSynchronize(sel[i]) == hipSuccess) && ok;
+        ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
+        if (!ok) { rc = -100; (void)hipStreamDestroy(s); break; }
+        bool overlaps_all = stamps[2 * k + 1] > stamps[2 * k];
+        for (int i = 0; i < k; ++i)
+            overlaps_all = overlaps_all && stamps[2 * k] < stamps[2 * i + 1] && stamps[2 * i] < stamps[2 * k + 1];
+        (overlaps_all ? sel : rejected).push_back(s);
+    }
+    const int found = (int)sel.size();
+    // fewer hardware queues than asked for: the remaining streams are ordinary ones (they share a queue with somebody)
+    while (!rc && (int)sel.size() < count) {
+        if (!rejected.empty()) {
+            sel.push_back(rejected.back());
+            rejected.pop_back();
+        } else {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) rc = -100;
+            else sel.push_back(s);
+        }
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    (void)hipHostFree(stamps);
+    if (rc) {
+        for (hipStream_t s : sel) (void)hipStreamDestroy(s);
+        return rc;
+    }
+    for (int i = 0; i < count; ++i) streams_out[i] = (void*)sel[i];
+    if (nconcurrent) *nconcurrent = found;
+    return 0;
+}
+
+int idahip_release_streams(int device, int count, void** streams) {
+    if (!streams || count < 0) return -2;
+    DevGuard dev_guard__(device);
+    int rc = 0;
+    for (int i = 0; i < count; ++i)
+        if (streams[i] && hipStreamDestroy((hipStream_t)streams[i]) != hipSuccess) rc = -100;
+    return rc;
+}
+
 int idahip_set_tolerances(idahip_ctx* c, double rtol, const double* hAtol, int natol) {
     DevGuard dev_guard__(c);
     if (!c || !hAtol) return -1;

@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
@@ -79,6 +79,8 @@ def load():
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     H.idahip_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp]
     H.idahip_destroy.argtypes = [vp]
+    H.idahip_concurrent_streams.argtypes = [ci, ci, C.POINTER(vp), C.POINTER(ci)]
+    H.idahip_release_streams.argtypes = [ci, ci, C.POINTER(vp)]
     H.idahip_last_error.argtypes = [vp]
     H.idahip_last_error.restype = C.c_char_p
     H.idahip_sync.argtypes = [vp]
@@ -618,3 +620,21 @@ def solve_schedule_group(ensembles, touts, max_rounds=0):
         texts = [(e.E.idaens_last_error(e.h) or b"").decode() for e in ensembles]
         raise IdaHipError("idaens_solve_schedule_group failed (%d): %s" % (rc, " | ".join(t for t in texts if t)))
     return list(zip(status, tret, reached))
+
+
+def concurrent_streams(count, device=0):
+    """idahip_concurrent_streams: `count` HIP streams for the contexts of a group, chosen so that the device really runs them
+    side by side. -> (list of stream handles for Ctx(..., stream=s), number of mutually concurrent ones)."""
+    H, _ = load()
+    arr = (C.c_void_p * count)()
+    nc = C.c_int(0)
+    rc = H.idahip_concurrent_streams(int(device), int(count), arr, C.byref(nc))
+    if rc != 0:
+        raise IdaHipError("idahip_concurrent_streams failed (%d)" % rc)
+    return [C.c_void_p(arr[i]) for i in range(count)], nc.value
+
+
+def release_streams(streams, device=0):
+    H, _ = load()
+    arr = (C.c_void_p * len(streams))(*[s.value if isinstance(s, C.c_void_p) else s for s in streams])
+    H.idahip_release_streams(int(device), len(streams), arr)

@@ -211,32 +211,51 @@ def linear_dense_slices(n=512, batch=4096, first=0, procs=1, slice_bytes=1 << 31
             yield (s0,) + tuple(arrays)
 
 
-def make_ctx_linear_dense_streamed(n, batch, first=0, procs=1, device=0, stream=None, keep=0, slice_bytes=1 << 31):
-    """Device context of `batch` config-3 systems [first, first + batch) whose matrices go from the generator to the device a
-    slice at a time (linear_dense_slices). Returns (ctx, prob): prob has everything linear_dense returns except that "A" and
-    "B" only hold the first `keep` systems (the calibration sample / the CPU baseline's sample)."""
+def make_ctxs_linear_dense_streamed(n, first, count, parts, procs=1, device=0, keep=0, slice_bytes=1 << 31):
+    """Device contexts for the config-3 systems [first, first + count), generated ONCE, slice by slice (linear_dense_slices), and
+    uploaded to every part that covers them. parts: [(offset, cnt, stream)] -- the context of part i holds systems
+    [first + offset, first + offset + cnt) on HIP stream `stream` (None: its own); parts may overlap (bench.py: the groups of a
+    rank, and one context with all of the rank's systems for the kernel timers). Returns [(ctx, prob)]: prob has everything
+    linear_dense returns for its systems except that "A" and "B" only hold the first `keep` systems of the whole range and only
+    in parts that start at offset 0 (the calibration sample / the CPU baseline's sample)."""
     from . import Ctx
-    if procs > 1 and batch >= 2 * procs:
-        ensure_fork_server()  # before the device context exists: the server's exec must not come from a GPU process
-    ctx = Ctx("linear_dense", n, batch, device=device, stream=stream)
+    if procs > 1 and count >= 2 * procs:
+        ensure_fork_server()  # before the device contexts exist: the server's exec must not come from a GPU process
     rtol, atol = 1.0e-6, np.array([1.0e-8])
-    ctx.set_tolerances(rtol, atol)
-    c, y0, yp0 = np.empty((batch, n)), np.empty((batch, n)), np.empty((batch, n))
-    keep = min(keep, batch)
+    ctxs = []
+    for off, cnt, stream in parts:
+        assert 0 <= off and off + cnt <= count and cnt >= 1
+        c_ = Ctx("linear_dense", n, cnt, device=device, stream=stream)
+        c_.set_tolerances(rtol, atol)
+        ctxs.append(c_)
+    c, y0, yp0 = np.empty((count, n)), np.empty((count, n)), np.empty((count, n))
+    keep = min(keep, count)
     Ak, Bk = np.empty((keep, n, n)), np.empty((keep, n, n))
     up = max(1, (1 << 28) // (8 * n * n))  # <= 256 MiB per matrix upload
-    for s0, A, Bm, cs, ys, yps in linear_dense_slices(n, batch, first, procs, slice_bytes):
-        cnt = A.shape[0]
-        for f in range(0, cnt, up):
-            ctx.set_linear_dense(A[f:f + up], Bm[f:f + up], cs[f:f + up], first=s0 + f)
-        c[s0:s0 + cnt], y0[s0:s0 + cnt], yp0[s0:s0 + cnt] = cs, ys, yps
+    for s0, A, Bm, cs, ys, yps in linear_dense_slices(n, count, first, procs, slice_bytes):
+        cnt_s = A.shape[0]
+        for c_, (off, cnt, _) in zip(ctxs, parts):
+            lo, hi = max(s0, off), min(s0 + cnt_s, off + cnt)  # the part's systems inside this slice
+            for f in range(lo, hi, up):
+                g = min(hi, f + up)
+                c_.set_linear_dense(A[f - s0:g - s0], Bm[f - s0:g - s0], cs[f - s0:g - s0], first=f - off)
+        c[s0:s0 + cnt_s], y0[s0:s0 + cnt_s], yp0[s0:s0 + cnt_s] = cs, ys, yps
         if s0 < keep:
-            m = min(cnt, keep - s0)
+            m = min(cnt_s, keep - s0)
             Ak[s0:s0 + m], Bk[s0:s0 + m] = A[:m], Bm[:m]
         del A, Bm, cs, ys, yps
-    prob = {"kind": "linear_dense", "n": n, "A": Ak, "B": Bk, "c": c, "yy0": y0, "yp0": yp0, "rtol": rtol, "atol": atol,
-            "touts": 0.1 * np.arange(1, 11), "matrices_on_host": keep}
-    return ctx, prob
+    out = []
+    for c_, (off, cnt, _) in zip(ctxs, parts):
+        k_ = min(keep, cnt) if off == 0 else 0
+        out.append((c_, {"kind": "linear_dense", "n": n, "A": Ak[:k_], "B": Bk[:k_], "c": c[off:off + cnt], "yy0": y0[off:off + cnt],
+                         "yp0": yp0[off:off + cnt], "rtol": rtol, "atol": atol, "touts": 0.1 * np.arange(1, 11), "matrices_on_host": k_}))
+    return out
+
+
+def make_ctx_linear_dense_streamed(n, batch, first=0, procs=1, device=0, stream=None, keep=0, slice_bytes=1 << 31):
+    """One device context of `batch` config-3 systems [first, first + batch) whose matrices go from the generator to the device a
+    slice at a time. Returns (ctx, prob): see make_ctxs_linear_dense_streamed."""
+    return make_ctxs_linear_dense_streamed(n, first, batch, [(0, batch, stream)], procs, device, keep, slice_bytes)[0]
 
 
 def heat1d(n=4096, batch=256):

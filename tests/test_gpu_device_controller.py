@@ -184,21 +184,22 @@ def test_device_lock_step_schedule_outputs_resume_and_stream():
     assert pd > 0
 
 
-@pytest.mark.parametrize("n,batch", [(48, 20), (200, 6)])
+@pytest.mark.parametrize("n,batch", [(48, 20), (200, 16)])
 def test_switching_steppers_between_round_limited_calls(n, batch):
     """A round-limited call of the device lock-step stepper can leave a system INSIDE an attempt whose Newton solve has to
     start over with a linear setup in the next round (newton_retry, round_ida.hpp). The next call may run on the host stepper
     (idaens_set_device_controller(0), roots, tracing ...): it must continue that attempt -- not begin it again. One round per
     call, the stepper alternating from call to call, against the device stepper run alone.
     A linear problem never takes that path by itself (a stale Jacobian contracts at |1 - cjratio| / (1 + cjratio) <= 0.25), so
-    the test makes the Jacobians stale the hard way: after six rounds the user replaces A by 3 A (idahip_set_linear_dense
-    between two solve calls). Every system whose next Newton solve starts on its old factors then diverges (rate > 0.9,
-    ConvergenceRecover with jcur == false) -- in a device round, since the seventh call is one -- and starts over in the call after
+    the test makes the Jacobians stale the hard way: after thirty rounds -- the step sizes have settled by then and most steps
+    reuse their factors; in the first rounds h doubles every step and every step sets up anew -- the user replaces A by 3 A
+    (idahip_set_linear_dense between two solve calls). Every system whose next Newton solve starts on its old factors then diverges (rate > 0.9,
+    ConvergenceRecover with jcur == false) -- in a device round, since call number thirty (counted from zero) is one -- and starts over in the call after
     it, which runs on the host stepper."""
     from idahip import problems
     prob = problems.linear_dense(n=n, batch=batch, procs=1)
     touts = prob["touts"]
-    R0 = 6
+    R0 = 30
 
     def swap(ctx):
         ctx.set_linear_dense(3.0 * prob["A"], prob["B"], prob["c"])
@@ -206,7 +207,7 @@ def test_switching_steppers_between_round_limited_calls(n, batch):
     cd, dev = make(prob, 1)
     yd = np.full((len(touts), batch, n), np.nan)
     s, t, r, yo, ypo = dev.solve_schedule(touts, max_rounds=R0, outputs=True)
-    assert (s == 99).all(), "six rounds do not finish the schedule"
+    assert (s == 99).all(), "thirty rounds do not finish the schedule"
     m = ~np.isnan(yo)
     yd[m] = yo[m]
     assert int(dev.counter("nls_nconvfails").sum()) == 0

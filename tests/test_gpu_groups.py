@@ -83,3 +83,45 @@ def test_a_group_needs_a_context_per_ensemble():
         idahip.stream_group([a, a], prob["touts"], 2)
     a.close()
     ctx.close()
+
+
+def test_streamed_contexts_for_overlapping_parts_hold_the_same_systems():
+    """problems.make_ctxs_linear_dense_streamed (bench.py's input path): the systems generated once, slice by slice, and
+    uploaded to every part that covers them -- three groups and one context with all of them. Integrating on those contexts
+    gives what integrating problems.linear_dense's arrays gives."""
+    import idahip
+    from idahip import problems
+    n, first, count = 32, 100, 23
+    parts = [(0, 8, None), (8, 8, None), (16, 7, None), (0, 23, None)]
+    made = problems.make_ctxs_linear_dense_streamed(n, first, count, parts, procs=1, keep=5, slice_bytes=16 * n * n * 5)  # five systems per slice
+    ref = problems.linear_dense(n=n, batch=count, first=first, procs=1)
+    c0 = problems.make_ctx(ref)
+    e0 = idahip.Ensemble(c0, ref["yy0"], ref["yp0"])
+    st, _, _ = e0.solve_schedule(ref["touts"][:3])
+    assert (st == 0).all()
+    assert np.array_equal(made[0][1]["A"], ref["A"][:5]) and made[1][1]["A"].shape[0] == 0 and np.array_equal(made[3][1]["B"], ref["B"][:5])
+    for (ctx, prob), (off, cnt, _) in zip(made, parts):
+        assert np.array_equal(prob["yy0"], ref["yy0"][off:off + cnt]) and np.array_equal(prob["c"], ref["c"][off:off + cnt])
+        e = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
+        st, _, _ = e.solve_schedule(ref["touts"][:3])
+        assert (st == 0).all()
+        assert np.array_equal(e.yy(), e0.yy()[off:off + cnt]) and np.array_equal(e.counter("nni"), e0.counter("nni")[off:off + cnt])
+        e.close()
+        ctx.close()
+    e0.close()
+    c0.close()
+
+
+def test_concurrent_streams_are_usable_and_distinct():
+    import idahip
+    streams, nconc = idahip.concurrent_streams(4)
+    assert len(streams) == 4 and len({s.value for s in streams}) == 4 and 1 <= nconc <= 4
+    from idahip import problems
+    prob = problems.linear_dense(n=24, batch=4, procs=1)
+    ctx = problems.make_ctx(prob, stream=streams[3])
+    e = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
+    st, _ = e.solve(0.1)
+    assert (st == 0).all()
+    e.close()
+    ctx.close()
+    idahip.release_streams(streams)

@@ -58,8 +58,12 @@ def main():
         G, pad = (int(x) for x in (cfg.split(":") + ["0"])[:2])
         os.environ["IDAHIP_TRAIL_LDS_PAD"] = str(pad)  # read by idahip_create: occupancy knob of the trailing kernel
         per = B // G
-        groups = [Half(n, per, g * per, stagger, mkstream()) for g in range(G)]
-        print("---- %d groups, trailing-kernel LDS pad %d" % (G, pad), flush=True)
+        if os.environ.get("PLAIN_STREAMS") == "1":
+            streams, nconc = [mkstream() for g in range(G)], -1
+        else:
+            streams, nconc = idahip.concurrent_streams(G)  # probed: really side by side on the device
+        groups = [Half(n, per, g * per, stagger, streams[g]) for g in range(G)]
+        print("---- %d groups, trailing-kernel LDS pad %d, mutually concurrent streams %d" % (G, pad, nconc), flush=True)
         h = groups[0]
         i0 = h.iters(); t0 = time.perf_counter(); h.run(K); dt = time.perf_counter() - t0
         print("one group of %d alone: %.1f ms/round, %.1f k iters/s" % (per, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
