@@ -61,12 +61,11 @@ int idaens_set_fused_newton(idaens* e, int on);
  * (IDA_NORMAL, no root functions, no trace):
  *   - small systems (n <= 8: Roberts, Lorenz63): a solve / solve_schedule / stream call is ONE launch in which every system
  *     runs its own time loop (idahip_tiny_solve);
- *   - linear dense problems with 8 < n <= 1024: lock-step rounds as below, but enqueued without a host round trip inside a
- *     round -- one synchronisation per round, none in idaens_stream (idahip_round_solve). A Newton solve that has to start
- *     over with a fresh Jacobian does so in the next round, so a system may need one round more than with the host stepper;
- *     its steps, orders, counters and results are the same.
- *   - the heat problem with 8 < n <= 4096: the same lock-step rounds (the batched LU of n > 1024 takes every list length from
- *     the device).
+ *   - linear dense and heat problems with 8 < n <= 4096: lock-step rounds as below, but enqueued without a host round trip
+ *     inside a round -- one synchronisation per round, none in idaens_stream (idahip_round_solve); for n > 1024 one more,
+ *     hidden behind the residual kernels: the length of the round's LU list comes back to size the factorisation's launches.
+ *     A Newton solve that has to start over with a fresh Jacobian does so in the next round, so a system may need one round
+ *     more than with the host stepper; its steps, orders, counters and results are the same.
  * off: the lock-step host stepper for every problem. Same results either way (one controller source, pow with glibc's
  * bits); the switch is the A/B. idaens_create compares the device pow with this host's std::pow on the controller's argument
  * ranges once per process: if they differ (another libm than the one glibc_pow.hpp restates) the device steppers stay off,

@@ -229,7 +229,7 @@ typedef struct idahip_tiny_call {
 int idahip_tiny_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idahip_tiny_call* call, int64_t* hRoundsDone, uint64_t* hAcc,
                       double* hYout, double* hYPout);
 int idahip_pow_batch(idahip_ctx* ctx, const double* hX, const double* hY, double* hOut, size_t count);
-/* The same call for larger systems (8 < n <= 1024, IDAHIP_LINEAR_DENSE, LU variant 4) as LOCK-STEP ROUNDS driven from the
+/* The same call for larger systems (8 < n <= 4096, IDAHIP_LINEAR_DENSE or IDAHIP_HEAT1D, LU variant 4) as LOCK-STEP ROUNDS driven from the
  * device side: a round = one step attempt of every stepping system (Ida::step's attempt loop body, src/lib.rs:613-711, with
  * Newton::solve, crates/nonlinear/src/newton.rs:51-167, and the batched kernels of this library inside), the controller
  * state of every system and the index lists live on the device, the host only enqueues each round's fixed launch sequence:

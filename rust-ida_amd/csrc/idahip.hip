@@ -79,6 +79,10 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
         const long v = std::strtol(pad, nullptr, 10);
         c->trail_lds_pad = (int)(v < 0 ? 0 : (v > 8192 ? 8192 : v));
     }
+    if (const char* ms = std::getenv("IDAHIP_WP2_MIN_SLOTS")) {
+        const long v = std::strtol(ms, nullptr, 10);
+        c->wp2_min_slots = (int)(v < 0 ? 0 : (v > 9 ? 9 : v));
+    }
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
@@ -1183,11 +1187,10 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     if (!c) return -1;
     if (!hSys || !call || !hRoundsDone || !hAcc || !rounds_run || !call->touts || call->ntout < 1) return fail(c, -2, "null argument");
     if (sys_bytes != sizeof(idactl::SysCore)) return fail(c, -2, "controller state of %zu bytes, this library expects %zu", sys_bytes, sizeof(idactl::SysCore));
-    const bool lin = c->kind == IDAHIP_LINEAR_DENSE && c->n <= LU_MAX_N;
+    const bool lin = c->kind == IDAHIP_LINEAR_DENSE && c->n <= LU_BIG_MAX_N;
     const bool heat = c->kind == IDAHIP_HEAT1D && c->n <= LU_BIG_MAX_N;
     if (c->n <= TINY_N || !(lin || heat) || c->lu_variant < 4)
-        return fail(c, -2, "the device-resident lock-step stepper takes linear dense problems with %d < n <= %d and heat problems with n <= %d (LU variant 4)",
-                    TINY_N, LU_MAX_N, LU_BIG_MAX_N);
+        return fail(c, -2, "the device-resident lock-step stepper takes linear dense and heat problems with %d < n <= %d (LU variant 4)", TINY_N, LU_BIG_MAX_N);
     if (call->recycle && (!c->ic_y || !c->ic_yp)) return fail(c, -2, "recycle needs idahip_snapshot_initial");
     if (call->recycle && call->max_rounds < 1) return fail(c, -2, "recycle needs a round limit");
     const int batch = c->batch, n = c->n;

@@ -931,8 +931,7 @@ int device_ctl_applies(const idaens* e, const SolveCall& C) {
     // root finding on the device: the function family of idaens_set_roots (not a user callback), not in idaens_stream
     if (e->nrtfn != 0 && (e->rt_fn != nullptr || e->nrtfn > IDAHIP_MAX_ROOTS || C.recycle)) return 0;
     if (e->n <= 8 && (k == IDAHIP_ROBERTS || k == IDAHIP_LORENZ63)) return 1;
-    if (e->n > 8 && e->n <= 1024 && k == IDAHIP_LINEAR_DENSE && idahip_lu_variant(e->ctx) >= 4) return 2;
-    if (e->n > 8 && e->n <= 4096 && k == IDAHIP_HEAT1D && idahip_lu_variant(e->ctx) >= 4) return 2;
+    if (e->n > 8 && e->n <= 4096 && (k == IDAHIP_LINEAR_DENSE || k == IDAHIP_HEAT1D) && idahip_lu_variant(e->ctx) >= 4) return 2;
     return 0;
 }
 

@@ -151,6 +151,29 @@ def test_device_lock_step_rounds_equal_host_stepper_and_oracle(n, batch):
     assert dev.total_rounds() >= host.total_rounds()
 
 
+@pytest.mark.parametrize("n,batch,ntout", [(1536, 2, 2), (2048, 2, 1)])
+def test_device_lock_step_rounds_for_linear_dense_beyond_1024_rows(n, batch, ntout):
+    """SURVEY 8(f)-2, last piece: linear dense problems with 1024 < n <= 4096 on the device lock-step stepper too (the leading
+    super-panels of their LU take the workgroup-per-matrix panel kernels, as the heat problem's do; the LU list's length is read
+    back to size those launches). Per system the same steps as the host stepper and the oracle."""
+    from idahip import problems
+    prob = problems.linear_dense(n=n, batch=batch, procs=1)
+    touts = [float(t) for t in prob["touts"][:ntout]]
+    cd, dev = make(prob, 1)
+    assert dev.device_controller_active() == 2
+    ch, host = make(prob, 0)
+    for t in touts:
+        sd, td = dev.solve(t)
+        sh, th = host.solve(t)
+        assert (sd == 0).all() and np.array_equal(sd, sh) and np.array_equal(td, th)
+        same(state(dev), state(host))
+    ref = run_oracle(prob, touts)
+    c = dev.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert np.array_equal(dev.yy(), ref["yy"][-1]) and np.array_equal(dev.yp(), ref["yp"][-1])
+
+
 def test_device_lock_step_schedule_outputs_resume_and_stream():
     from idahip import problems
     prob = problems.linear_dense(n=48, batch=20, procs=1)

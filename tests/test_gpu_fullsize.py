@@ -204,9 +204,9 @@ def test_config2_lorenz63_full_batch():
 @pytest.mark.parametrize("device_ctl", [1, 0])
 def test_config2_lorenz63_whole_horizon(device_ctl):
     """Config 2 exactly as BASELINE.json states it -- Lorenz63, N = 3, B = 1024 -- over its WHOLE horizon: all 50 outputs
-    t = 0.1 .. 5.0 against the oracle, y and y' at every output and every counter, step size and order at the end. The system
-    is chaotic: a one-ulp slip anywhere in the first outputs is a visibly different trajectory at t = 5 (and different step
-    counts well before). Device stepper (one thread per system) and host stepper."""
+    t = 0.1 .. 5.0 against the oracle, y and y' at every output and every counter, step size and order at the end (round 4
+    compared the first 20 outputs only; the late horizon is where a slip in the controller -- a step size, an order -- would have
+    had the longest time to show). Device stepper (one thread per system) and host stepper."""
     import idahip
     from idahip import problems
     p = problems.lorenz63(batch=1024)
@@ -228,8 +228,6 @@ def test_config2_lorenz63_whole_horizon(device_ctl):
         assert np.array_equal(c[k], ref["counters"][k]), k
     assert np.array_equal(c["kused"], ref["kused"]) and np.array_equal(ens.real("hused"), ref["hused"])
     assert np.array_equal(ens.yy(), ref["yy"][-1]) and np.array_equal(ens.yp(), ref["yp"][-1])
-    # trajectories really diverge over this horizon: the batch's 1e-3 spread of initial states is O(10) apart at t = 5
-    assert np.ptp(yo[-1][:, 0]) > 1.0
     for k in QUIRK_PATHS:
         assert int(c[k].sum()) == 0, k
     ens.close()
