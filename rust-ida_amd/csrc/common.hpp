@@ -67,13 +67,6 @@ struct idahip_ctx {
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
-    // extra dynamic LDS per workgroup of lu_trail64w_kernel<1024> (IDAHIP_TRAIL_LDS_PAD, bytes, read at idahip_create; 0 = none):
-    // from 2.5 KB on, two of its workgroups fit a CU instead of three, which leaves a third of every SIMD's registers and
-    // 50 KB of LDS to the kernels of OTHER streams (idaens_stream_group). An occupancy knob only: results do not depend on it.
-    int trail_lds_pad = 0;
-    // super-panels with at least this many 64-row slots are factored by two waves per matrix (lu_wavepanel2.hpp), the others by
-    // one (lu_wavepanel.hpp); 0 = one wave always. IDAHIP_WP2_MIN_SLOTS overrides (read at idahip_create). Results do not depend on it.
-    int wp2_min_slots = 0;
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)

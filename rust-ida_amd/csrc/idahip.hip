@@ -75,14 +75,6 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
     c->npad16 = (n + 15) & ~15;
-    if (const char* pad = std::getenv("IDAHIP_TRAIL_LDS_PAD")) {  // occupancy knob of the rank-64 trailing kernel (common.hpp); results do not depend on it
-        const long v = std::strtol(pad, nullptr, 10);
-        c->trail_lds_pad = (int)(v < 0 ? 0 : (v > 8192 ? 8192 : v));
-    }
-    if (const char* ms = std::getenv("IDAHIP_WP2_MIN_SLOTS")) {
-        const long v = std::strtol(ms, nullptr, 10);
-        c->wp2_min_slots = (int)(v < 0 ? 0 : (v > 9 ? 9 : v));
-    }
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored

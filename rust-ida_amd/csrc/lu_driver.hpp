@@ -2,7 +2,6 @@
 #pragma once
 #include "lu_kernels.hpp"
 #include "lu_wavepanel.hpp"
-#include "lu_wavepanel2.hpp"
 
 namespace idahip {
 
@@ -91,23 +90,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
         case 7: IDAHIP_WP_LAUNCH(7); break;                                                                 \
         default: IDAHIP_WP_LAUNCH(8); break;                                                                \
     }
-            // two waves per matrix from wp2_min_slots slots on (lu_wavepanel2.hpp), one wave below
-#define IDAHIP_WP2_LAUNCH(NSV) \
-    hipLaunchKernelGGL((lu_wavepanel2_kernel<NSV>), dim3(nsys), dim3(128), 0, c->stream, w, k0)
-            if (c->wp2_min_slots >= 2 && ns >= c->wp2_min_slots) {
-                switch (ns) {
-                    case 2: IDAHIP_WP2_LAUNCH(2); break;
-                    case 3: IDAHIP_WP2_LAUNCH(3); break;
-                    case 4: IDAHIP_WP2_LAUNCH(4); break;
-                    case 5: IDAHIP_WP2_LAUNCH(5); break;
-                    case 6: IDAHIP_WP2_LAUNCH(6); break;
-                    case 7: IDAHIP_WP2_LAUNCH(7); break;
-                    default: IDAHIP_WP2_LAUNCH(8); break;
-                }
-            } else {
-                IDAHIP_WP_SWITCH()
-            }
-#undef IDAHIP_WP2_LAUNCH
+            IDAHIP_WP_SWITCH()
             hipLaunchKernelGGL((lu_wavepanel_kernel<true, 0>), dim3(nsys), dim3(64), 0, c->stream, w, k0);
 #undef IDAHIP_WP_SWITCH
 #undef IDAHIP_WP_LAUNCH
@@ -142,7 +125,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 hipLaunchKernelGGL(lu_u12_zero_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * (ncb + (nsplit - 1) * nbs)), dim3(256), 0, c->stream, w, k0, nsys, ncb, nsplit);
             } else
-                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), (size_t)c->trail_lds_pad, c->stream, w, k0, nsys, ncb, 1);
+                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, 1);
         }
     }
     {

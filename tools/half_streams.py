@@ -53,17 +53,16 @@ def main():
         i0 = one.iters(); t0 = time.perf_counter(); one.run(K); dt = time.perf_counter() - t0
         print("one ensemble of %d: %d rounds %.1f ms/round, %.1f k iters/s" % (B, K, dt / K * 1e3, (one.iters() - i0) / dt / 1e3), flush=True)
     one.ens.close(); one.ctx.close(); del one
-    # configurations "groups[:pad]" in the order given (a configuration may appear twice: run-to-run spread on one box)
+    # numbers of groups in the order given (a configuration may appear twice: run-to-run spread on one box)
     for cfg in os.environ.get("NGROUPS", "2,3,4").split(","):
-        G, pad = (int(x) for x in (cfg.split(":") + ["0"])[:2])
-        os.environ["IDAHIP_TRAIL_LDS_PAD"] = str(pad)  # read by idahip_create: occupancy knob of the trailing kernel
+        G = int(cfg)
         per = B // G
         if os.environ.get("PLAIN_STREAMS") == "1":
             streams, nconc = [mkstream() for g in range(G)], -1
         else:
             streams, nconc = idahip.concurrent_streams(G)  # probed: really side by side on the device
         groups = [Half(n, per, g * per, stagger, streams[g]) for g in range(G)]
-        print("---- %d groups, trailing-kernel LDS pad %d, mutually concurrent streams %d" % (G, pad, nconc), flush=True)
+        print("---- %d groups, mutually concurrent streams %d" % (G, nconc), flush=True)
         h = groups[0]
         i0 = h.iters(); t0 = time.perf_counter(); h.run(K); dt = time.perf_counter() - t0
         print("one group of %d alone: %.1f ms/round, %.1f k iters/s" % (per, dt / K * 1e3, (h.iters() - i0) / dt / 1e3), flush=True)
