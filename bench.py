@@ -539,28 +539,31 @@ def main():
     # the ensemble is sharded, unlike the state of a stream after K rounds; it reuses the stream's device context, so it comes
     # after everything that continues the stream), rank 0 gathers digests of every rank's block
     # and its counter sums -- a shard with wrong inputs or a wrong device shows here -- and, on request, the arrays themselves.
-    vp = run.whole_pass(4)
-    vcnt = vp["counts"]  # rows: nst, netf, ncfn, nni, nsetups, kused
+    # (not in the profile runs -- IDAHIP_BENCH_TIME_ALL=1 --: the kernel trace of such a run is compared with the timers' totals,
+    # and the timers are off during a whole pass)
+    want_vp = not TIME_ALL
+    vp = run.whole_pass(4) if want_vp else None
+    vcnt = vp["counts"] if want_vp else np.zeros((6, count), dtype=np.int64)  # rows: nst, netf, ncfn, nni, nsetups, kused
     shard = {"rank": rank, "first": first, "count": count, "device": device_record(torch, local_rank),
              "input_generation_s": round(t_gen, 1), "sum_nst": int(vcnt[0].sum()), "sum_nni": int(vcnt[3].sum()), "sum_nsetups": int(vcnt[4].sum()),
-             "sha256_yy": hashlib.sha256(np.ascontiguousarray(vp["yy"]).tobytes()).hexdigest(),
-             "sha256_counters": hashlib.sha256(np.ascontiguousarray(vcnt).tobytes()).hexdigest()}
+             "sha256_yy": hashlib.sha256(np.ascontiguousarray(vp["yy"]).tobytes()).hexdigest() if want_vp else None,
+             "sha256_counters": hashlib.sha256(np.ascontiguousarray(vcnt).tobytes()).hexdigest() if want_vp else None}
     shards = [shard]
-    blocks = [(vcnt, vp["yy"], vp["yp"])] if args.results_npz else None
+    blocks = [(vcnt, vp["yy"], vp["yp"])] if (args.results_npz and want_vp) else None
     if world > 1:
         shards = [None] * world
         dist.all_gather_object(shards, shard)
-        if args.results_npz:
+        if args.results_npz and want_vp:
             blocks = [None] * world
             dist.all_gather_object(blocks, (vcnt, vp["yy"], vp["yp"]))
-    if rank == 0 and args.results_npz:
+    if rank == 0 and args.results_npz and want_vp:
         np.savez(args.results_npz, first=np.array([sh["first"] for sh in shards]), counts=np.concatenate([b[0] for b in blocks], axis=1),
                  yy=np.concatenate([b[1] for b in blocks], axis=0), yp=np.concatenate([b[2] for b in blocks], axis=0))
 
 
     extras = None
     if world == 1 and not args.no_extras:
-        passes = [vp] + [run.whole_pass(4) for _ in range(max(1, args.passes) - 1)]
+        passes = ([vp] if want_vp else []) + [run.whole_pass(4) for _ in range(max(1, args.passes) - (1 if want_vp else 0))]
         rates = [p["iters"] / p["seconds"] for p in passes]
         # the same passes with one host round trip per Newton iteration (idaens_set_fused_newton(0)): the before/after of the
         # device-side convergence tests (first slice); identical work and results, only the pace changes
@@ -686,7 +689,7 @@ def main():
                                                  "devices": [sh["device"] for sh in shards],
                                                  "generator_processes": procs, "cores_available_to_rank0": cores,
                                                  "process_group": backend + " (barrier and two scalars only; no data-path collective)"},
-            "ensemble_result": {
+            "ensemble_result": None if not want_vp else {
                 "systems": sum(sh["count"] for sh in shards), "shards": [{k: sh[k] for k in ("rank", "first", "count", "sum_nst", "sum_nni", "sum_nsetups", "sha256_yy", "sha256_counters")} for sh in shards],
                 "sum_nst": sum(sh["sum_nst"] for sh in shards), "sum_nni": sum(sh["sum_nni"] for sh in shards),
                 "note": "SURVEY 8(e): every rank integrates its shard once from fresh state through the whole schedule (untimed) and rank 0 "

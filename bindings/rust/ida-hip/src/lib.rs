@@ -22,7 +22,7 @@
 //! caught and turned into a failed call.
 use std::ffi::CStr;
 use std::marker::PhantomData;
-use std::os::raw::{c_double, c_int, c_void};
+use std::os::raw::{c_double, c_int, c_long, c_void};
 use std::panic::{catch_unwind, AssertUnwindSafe};
 use std::ptr;
 
@@ -154,8 +154,13 @@ unsafe impl Send for Ctx {}
 
 impl Ctx {
     pub fn new(device: i32, n: usize, batch: usize, problem: Problem) -> Result<Self, Error> {
+        Self::new_on_stream(device, n, batch, problem, ptr::null_mut())
+    }
+
+    /// A context on a HIP stream of the caller's (one of `concurrent_streams`' for the ensembles of a group); null = its own.
+    pub fn new_on_stream(device: i32, n: usize, batch: usize, problem: Problem, hip_stream: *mut c_void) -> Result<Self, Error> {
         let mut raw: *mut sys::idahip_ctx = ptr::null_mut();
-        let rc = unsafe { sys::idahip_create(&mut raw, device, n as c_int, batch as c_int, problem.code(), ptr::null_mut()) };
+        let rc = unsafe { sys::idahip_create(&mut raw, device, n as c_int, batch as c_int, problem.code(), hip_stream) };
         if rc != 0 || raw.is_null() {
             return Err(Error::Library { code: rc, message: "idahip_create failed (no GPU visible, or bad size)".to_string() });
         }
@@ -554,6 +559,42 @@ impl HipEnsemble {
     pub fn device_controller_active(&self) -> i32 {
         unsafe { sys::idaens_device_controller_active(self.raw) as i32 }
     }
+}
+
+/// `count` HIP streams that the device runs side by side (`idahip_concurrent_streams`: the HIP runtime may put two ordinary
+/// streams on one hardware queue); the second value is how many of them, from the front, are mutually concurrent. The caller
+/// owns the handles: `release_streams` after the contexts created on them are gone.
+pub fn concurrent_streams(device: i32, count: usize) -> Result<(Vec<*mut c_void>, usize), Error> {
+    let mut out: Vec<*mut c_void> = vec![ptr::null_mut(); count];
+    let mut nc: c_int = 0;
+    let rc = unsafe { sys::idahip_concurrent_streams(device, count as c_int, out.as_mut_ptr(), &mut nc) };
+    if rc != 0 {
+        return Err(Error::Library { code: rc, message: "idahip_concurrent_streams failed".to_string() });
+    }
+    Ok((out, nc as usize))
+}
+
+pub fn release_streams(device: i32, streams: &mut [*mut c_void]) {
+    unsafe {
+        sys::idahip_release_streams(device, streams.len() as c_int, streams.as_mut_ptr());
+    }
+}
+
+/// `idaens_stream_group`: throughput mode for several ensembles of ONE device at once, one host thread and HIP stream each
+/// (every system is integrated exactly as alone; the groups fill each other's idle stretches of a lock-step round).
+/// Returns the integrations completed per group.
+pub fn stream_group(ens: &mut [HipEnsemble], touts: &[f64], max_rounds: i64, stagger_rounds: i64, offset_us: i64) -> Result<Vec<i64>, Error> {
+    let mut raws: Vec<*mut sys::idaens> = ens.iter().map(|e| e.raw).collect();
+    let mut done = vec![0i64; ens.len()];
+    let rc = unsafe {
+        sys::idaens_stream_group(raws.as_mut_ptr(), raws.len() as c_int, touts.as_ptr(), touts.len() as c_int, max_rounds as c_long,
+                                 stagger_rounds as c_long, offset_us as c_long, done.as_mut_ptr())
+    };
+    if rc < 0 {
+        let text = ens.iter().map(|e| e.last_error()).filter(|t| !t.is_empty()).collect::<Vec<_>>().join(" | ");
+        return Err(Error::Library { code: rc, message: text });
+    }
+    Ok(done)
 }
 
 impl Drop for HipEnsemble {

@@ -4,7 +4,7 @@
 # the control kernels) can be read off. usage: tools/round_trace.sh <tag> [bench.py arguments]
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/r4/rt_$TAG
+OUT=$ROOT/gpurun_out/${ROUND_DIR:-r5}/rt_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export IDAHIP_GEN_PROCS=1
