@@ -67,6 +67,10 @@ struct idahip_ctx {
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
+    // more than 1024 live rows: 1 (default) = a 64-column super-panel is one launch of lu_superpanel_kernel; 0 = round 4's eight
+    // 8-column panel launches with a narrow update after each (IDAHIP_LU_SUPERPANEL=0 at idahip_create: the A/B and the cross-check
+    // in the tests). Bit-identical factors either way.
+    int lu_superpanel = 1;
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)

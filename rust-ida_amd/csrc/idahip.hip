@@ -75,6 +75,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
     c->npad16 = (n + 15) & ~15;
+    if (const char* sp = std::getenv("IDAHIP_LU_SUPERPANEL")) c->lu_superpanel = std::strtol(sp, nullptr, 10) != 0 ? 1 : 0;
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored

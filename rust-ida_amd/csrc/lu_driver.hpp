@@ -2,6 +2,7 @@
 #pragma once
 #include "lu_kernels.hpp"
 #include "lu_wavepanel.hpp"
+#include "lu_superpanel.hpp"
 
 namespace idahip {
 
@@ -43,6 +44,16 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
             // the super-panel
             KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             const int cend = (k0 + 64 < n) ? k0 + 64 : n;
+            if (c->lu_superpanel) {
+                // the whole super-panel in one launch (lu_superpanel.hpp), eight rows per lane above LU_WIDE_ROWS live rows, four below (up to 512 threads)
+                if (n - k0 > LU_WIDE_ROWS) {
+                    const int threads = (((n - k0 + 7) / 8 + 63) / 64) * 64;
+                    hipLaunchKernelGGL((lu_superpanel_kernel<8, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+                } else {
+                    const int threads = (((n - k0 + 3) / 4 + 63) / 64) * 64;
+                    hipLaunchKernelGGL((lu_superpanel_kernel<4, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
+                }
+            } else {
             auto narrow_split = [&](int kk, int nbs) {
                 // one column block per matrix: the row tiles are dealt to several workgroups (a launch of one workgroup per
                 // matrix leaves most of the chip idle at the batch sizes of large n)
@@ -72,6 +83,14 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                     }
                 }
             }
+            }  // !lu_superpanel
+        } else if (c->lu_superpanel && c->lu_variant >= 4 && n > LU_MAX_N && n - k0 >= 64) {
+            // large n (small batches): the remaining super-panels by the workgroup-per-matrix kernel too, two rows per lane -- a wave
+            // per matrix (lu_wavepanel) is made for thousands of matrices per call, and on banded matrices its FAST mode hands
+            // every super-panel to the one-wave SLOW launch (280 us each at ~100 matrices)
+            KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
+            const int threads = (((n - k0 + 1) / 2 + 63) / 64) * 64;
+            hipLaunchKernelGGL((lu_superpanel_kernel<2, 512, 2>), dim3(nsys), dim3(threads), 0, c->stream, w, k0);
         } else if (c->lu_variant >= 4 && n - k0 <= WP_MAX_ROWS) {
             KTimer kt(c, IDAHIP_K_LU_PANEL, nsys);
             // one wave per matrix factors the whole 64-column super-panel (lu_wavepanel.hpp); the second launch finishes
@@ -131,7 +150,8 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     {
         KTimer kt(c, IDAHIP_K_LU_FINALIZE, nsys);
         hipLaunchKernelGGL(lu_finalize_kernel, dim3(nsys, (n + 31) / 32), dim3(256), 0, c->stream, w, out, ostride, perm, 32, NB,
-                           n > LU_MAX_N ? 8 : 0, c->lu_variant >= 4 ? WP_MAX_ROWS : 0);  // (16 where <= LU_WIDE_ROWS rows were live)
+                           n > LU_MAX_N ? (c->lu_superpanel ? 64 : 8) : 0,  // (8: 16 where <= LU_WIDE_ROWS rows were live)
+                           c->lu_variant >= 4 ? ((c->lu_superpanel && n > LU_MAX_N) ? LU_MAX_N : WP_MAX_ROWS) : 0);  // super-panels factored 64 columns at a time
     }
     return 0;
 }

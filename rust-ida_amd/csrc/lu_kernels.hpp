@@ -1397,7 +1397,8 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
             // large n: the leading 64-column super-panels (more than LU_MAX_N live rows) are built from sp_lead-column panels
             // wp_rows > 0: super-panels with at most wp_rows live rows were factored 64 columns at a time (lu_wavepanel_kernel)
             const int liv = n - (p & ~63);  // live rows when the super-panel of pivot position p was factored
-            const int w_ = (wp_rows > 0 && liv <= wp_rows) ? 64 : (sp_lead > 0 && liv > LU_MAX_N) ? (liv > LU_WIDE_ROWS ? sp_lead : 2 * sp_lead) : sp;
+            // (sp_lead == 64: lu_superpanel_kernel factored those super-panels whole and their U rows inside the super-panel are in the work matrix)
+            const int w_ = (wp_rows > 0 && liv <= wp_rows) ? 64 : (sp_lead > 0 && liv > LU_MAX_N) ? (sp_lead >= 64 ? 64 : liv > LU_WIDE_ROWS ? sp_lead : 2 * sp_lead) : sp;
             const int spend = (p / w_ + 1) * w_;  // first column right of the panel that made row p a pivot row
             je = je < spend ? je : spend;
         }

@@ -136,10 +136,19 @@ def test_nan_and_infinity_follow_the_reference_scan(n):
     assert np.array_equal(lu[ok], lu_o[ok], equal_nan=True)
 
 
+@pytest.fixture(params=[1, 0], ids=["superpanel", "panel-by-panel"])
+def large_n_pipeline(request, monkeypatch):
+    """n > 1024: a 64-column super-panel as ONE launch of lu_superpanel_kernel (default, round 5) or as round 4's eight 8-column
+    panel launches with a narrow update after each (IDAHIP_LU_SUPERPANEL=0, read when a context is created): both against the
+    oracle, hence against each other."""
+    monkeypatch.setenv("IDAHIP_LU_SUPERPANEL", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("n", [1025, 1100, 1600, 2048])
-def test_lu_beyond_1024_rows(n):
-    """More than 1024 rows: the leading super-panels run with eight 8-column panels and eight rows per lane (whatever
-    the LU variant), the rest with the selected pipeline."""
+def test_lu_beyond_1024_rows(n, large_n_pipeline):
+    """More than 1024 rows: the super-panels are factored by the workgroup-per-matrix kernels (whatever the LU variant) -- whole, or
+    in eight 8-column panels with eight rows per lane."""
     rng = np.random.default_rng(n)
     B = 2
     mats = rng.standard_normal((B, n, n))
@@ -159,7 +168,7 @@ def test_lu_beyond_1024_rows(n):
 
 
 @pytest.mark.parametrize("n", [1536, 2120])
-def test_banded_and_partly_banded_matrices_beyond_1024_rows(n):
+def test_banded_and_partly_banded_matrices_beyond_1024_rows(n, large_n_pipeline):
     """The large-n trailing updates treat nearly empty U12 blocks apart (zero column blocks found by their own kernel, the
     rest applied one live row per thread, helpers sharing the rows once the first super-panel has shown a band): a
     tridiagonal matrix, a wider band that pivots, a band that turns dense after the first super-panel (helpers on the
@@ -189,6 +198,28 @@ def test_banded_and_partly_banded_matrices_beyond_1024_rows(n):
     ctx.ls_solve(dA, dP, dX, dB)
     x_o = np.array([O.getrs(lu_o[s], piv_o[s], rhs[s]) for s in range(B)])
     assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
+
+
+def test_nan_infinity_zero_pivot_and_ties_beyond_1024_rows(large_n_pipeline):
+    """The special cases of the pivot scan (dense.rs:111-122) in the large-n kernels: NaN at and off the pivot position, two
+    infinities in a column, exact ties in |a| between rows that different waves hold, an all-zero column (Err(k+1)), on matrices
+    with many exact zeros (the a_kj == 0 rule in the U slot and in the left-looking updates of lu_superpanel_kernel)."""
+    n = 1100
+    rng = np.random.default_rng(11)
+    m = rng.integers(-3, 4, size=(5, n, n)).astype(float)  # small integers: ties and zeros everywhere
+    m += np.eye(n) * 2.0
+    m[1, 700, 3] = np.nan          # NaN off the pivot position of its column
+    m[1, 70, 70] = np.nan          # NaN at the pivot position
+    m[2, 5, 64] = np.inf
+    m[2, 900, 64] = -np.inf        # two infinities in one column: the first in scan order wins
+    m[3, :, 130] = 0.0             # a zero column: zero pivot reported with its 1-based column, the other systems unaffected
+    m[4] = np.where(rng.random((n, n)) < 0.001, np.nan, m[4])
+    info_o, lu_o, piv_o = oracle_lu(m)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(m)
+    assert np.array_equal(info, info_o) and info_o[3] != 0
+    ok = info_o == 0
+    assert np.array_equal(piv[ok], piv_o[ok])
+    assert np.array_equal(lu[ok], lu_o[ok], equal_nan=True)
 
 
 def test_pivot_ties_resolve_like_the_reference_scan():
