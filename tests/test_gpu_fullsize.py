@@ -150,6 +150,35 @@ def test_config5_shard_inputs_match_the_oracle(shard):
     ens.close()
 
 
+def test_four_groups_side_by_side_equal_the_single_ensemble_at_full_size(full):
+    """The headline configuration as bench.py runs it since round 5 -- the 4096 systems as four ensembles of 1024 side by side, each
+    on its own context, probed-concurrent HIP stream and host thread (idaens_solve_schedule_group) -- against the single ensemble of
+    the fixture (which the oracle pins on its sample): every system's state, step size, order and counters, bit for bit."""
+    import idahip
+    from idahip import problems
+    prob = full["prob"]
+    G, per = 4, B // 4
+    streams, nconc = idahip.concurrent_streams(G)
+    assert nconc >= 2, "the device offered no two concurrent hardware queues"
+    subs = [sub_problem(prob, np.arange(g * per, (g + 1) * per)) for g in range(G)]
+    ctxs = [problems.make_ctx(s_, stream=streams[g]) for g, s_ in enumerate(subs)]
+    enss = [idahip.Ensemble(c, s_["yy0"], s_["yp0"]) for c, s_ in zip(ctxs, subs)]
+    res = idahip.solve_schedule_group(enss, full["touts"])
+    for status, tret, reached in res:
+        assert (status == 0).all() and (reached == len(full["touts"])).all() and np.array_equal(tret, np.full(per, full["tout"]))
+    cs = [e.counters() for e in enss]
+    for k in CNT + ("kused",):
+        assert np.array_equal(np.concatenate([c[k] for c in cs]), full["counters"][k]), k
+    assert np.array_equal(np.concatenate([e.yy() for e in enss]), full["yy"])
+    assert np.array_equal(np.concatenate([e.yp() for e in enss]), full["yp"])
+    assert np.array_equal(np.concatenate([e.real("hused") for e in enss]), full["hused"])
+    for e in enss:
+        e.close()
+    for c in ctxs:
+        c.close()
+    idahip.release_streams(streams)
+
+
 def test_stream_driver_at_full_n(full):
     """idaens_stream (the driver bench.py times) at N = 512: systems restart from their initial conditions when they reach
     t = 1; whatever pass a system is in, its accepted steps are those of the oracle's fresh integration."""
