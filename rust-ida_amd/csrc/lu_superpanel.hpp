@@ -104,6 +104,12 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_superpanel_kernel(LuWs w, const 
                 for (int j = 0; j < NB; ++j) a[i][j] = is_valid(i) ? a[i][j] : 0.0;
             }
         };
+        // the U slot's rows (wave 0: lane k = pivot row k of the super-panel), requested with the block: one round trip less per block
+        const bool uhas = wave == 0 && lane < lb;
+        const int urow = s_prow[uhas ? lane : 0];
+        double xu[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) xu[j] = buf_load_f64(rsrc, uhas ? (unsigned)urow * 8u : 0xfffffff0u, (kb + j) * n * 8);  // (other lanes: out of range, +0.0, no memory access)
         if (lb > NB) {
             // multipliers of the previous block's 8 pivot rows for the super-panel's columns left of that block: one entry per
             // thread (a serial read-back by the lanes that own those rows was a chain of lb / 8 round trips to memory per block)
@@ -119,13 +125,6 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_superpanel_kernel(LuWs w, const 
             __syncthreads();  // s_l11 is complete for the pivots 0 .. lb-1
             // ---- U slot (wave 0): rows k < lb of U in this block's columns
             if (wave == 0) {
-                const bool uhas = lane < lb;
-                const int urow = s_prow[uhas ? lane : 0];
-                double xu[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) xu[j] = buf_load_f64(rsrc, (unsigned)urow * 8u, (kb + j) * n * 8);
-#pragma unroll
-                for (int j = 0; j < NB; ++j) xu[j] = uhas ? xu[j] : 0.0;
                 int next = 0;
 #pragma unroll 1
                 for (;;) {
