@@ -72,6 +72,8 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
     // part -- they read +0.0 -- instead of a guarded load per column. Eight guarded loads are eight branches; the compiler's
     // wait-count bookkeeping then gives up and every step of the solve waits for ALL outstanding loads, the next group's
     // prefetch included: one trip to memory per eight steps, 5 us per diagonal block, 32 blocks per solve at n = 512.
+    // (32-bit byte counts and scalar offsets: exact up to the largest matrix this library factors, LU_BIG_MAX_N = 4096 -> 128 MiB)
+    static_assert((long long)LU_BIG_MAX_N * LU_BIG_MAX_N * 8 < (1ll << 31), "the buffer descriptor's 32-bit sizes and offsets assume n * n * 8 < 2^31");
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(LU), 0, STAGE ? 0 : n * n * 8, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     __shared__ int s_kfin;  // the entries of b the running column block multiplies with are all finite
@@ -93,7 +95,7 @@ __device__ __forceinline__ void wg_getrs(const double* __restrict__ LU, int n, d
                 for (int u = 0; u < UNR; ++u) {
                     const int k = k0 + u;
                     if (STAGE) l[u] = (k + 1 < kw && lane > k && lane < kw) ? dg[k * 64 + lane] : 0.0;
-                    else l[u] = buf_load_f64(rsrc, (k + 1 < kw && lane > k && lane < kw) ? (unsigned)i * 8u : OOB, __builtin_amdgcn_readfirstlane((kb + k) * n * 8));
+                    else l[u] = buf_load_f64(rsrc, (k + 1 < kw && lane > k && lane < kw) ? (unsigned)i * 8u : OOB, __builtin_amdgcn_readfirstlane((kb + (k < kw ? k : kw - 1)) * n * 8));  // (groups past the block's end: every lane out of range anyway; the scalar offset stays inside the matrix)
                 }
             };
             auto fwd = [&](const int k0, const double (&l)[UNR]) {

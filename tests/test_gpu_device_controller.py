@@ -292,6 +292,23 @@ def test_device_lock_step_rounds_for_the_heat_problem(n, batch, ntout):
     assert dev.total_rounds() >= host.total_rounds() > 0
 
 
+def test_heat_stream_beyond_1024_rows_on_both_steppers():
+    """Throughput mode for n > 1024 on the device lock-step stepper: there the round's LU-list length travels to the host (behind
+    the residual kernels) to size the factorisation's launches, also when the rounds are enqueued without any other
+    synchronisation. Same totals and states as the host stepper after the same rounds."""
+    from idahip import problems
+    prob = problems.heat1d(n=1100, batch=5)
+    touts = prob["touts"]
+    cd, dev = make(prob, 1)
+    ch, host = make(prob, 0)
+    for k, stag in ((9, 4), (1, 0), (7, 0)):
+        pd = dev.stream(touts, k, stagger_rounds=stag)
+        ph = host.stream(touts, k, stagger_rounds=stag)
+        assert dev.total_rounds() == host.total_rounds() and dev.total_newton_iters() == host.total_newton_iters() and pd == ph
+        same(state(dev), state(host))
+    assert dev.total_newton_iters() > 0
+
+
 def _run_with_roots(ens, touts, comps, thr, max_returns=400):
     """Ida::solve until every tout is reached, every return recorded (root returns do not advance the tout)."""
     ens.set_roots(comps, thr)

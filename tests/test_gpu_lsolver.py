@@ -200,6 +200,24 @@ def test_banded_and_partly_banded_matrices_beyond_1024_rows(n, large_n_pipeline)
     assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
 
 
+def test_solve_through_the_buffer_loads_with_a_partial_last_block_at_large_n():
+    """wg_getrs with 256 threads reads the diagonal blocks through a buffer descriptor with 32-bit byte counts and scalar
+    offsets (n * n * 8 and (kb + k) * n * 8: exact up to n = 4096) and prefetches column groups past the end of a partial last
+    block, whose lanes are all out of range. n = 2999: odd (one row per lane and load, the 256-thread kernel), 47 blocks, the
+    last one 55 columns wide, offsets up to 72 MB."""
+    n = 2999
+    rng = np.random.default_rng(2999)
+    mats = rng.standard_normal((1, n, n)) + np.eye(n) * 3.0
+    rhs = rng.standard_normal((1, n))
+    info_o, lu_o, piv_o = oracle_lu(mats)
+    ctx, dA, dP, rc, info, lu, piv = gpu_lu(mats)
+    assert rc == 0 and info_o[0] == 0 and np.array_equal(piv, piv_o) and np.array_equal(lu, lu_o)
+    dB = ctx.dev_array(rhs)
+    dX = ctx.dev_empty(rhs.nbytes)
+    ctx.ls_solve(dA, dP, dX, dB)
+    assert np.array_equal(ctx.to_host(dX, (1, n)), O.getrs(lu_o[0], piv_o[0], rhs[0])[None, :])
+
+
 def test_nan_infinity_zero_pivot_and_ties_beyond_1024_rows(large_n_pipeline):
     """The special cases of the pivot scan (dense.rs:111-122) in the large-n kernels: NaN at and off the pivot position, two
     infinities in a column, exact ties in |a| between rows that different waves hold, an all-zero column (Err(k+1)), on matrices
