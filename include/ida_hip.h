@@ -76,6 +76,10 @@ int idahip_destroy(idahip_ctx* ctx);
  * less than count when the runtime offers fewer hardware queues (GPU_MAX_HW_QUEUES, 4 by default). */
 int idahip_concurrent_streams(int device, int count, void** streams_out, int* nconcurrent);
 int idahip_release_streams(int device, int count, void** streams);
+/* Diagnostic: how evenly the device shares itself between two streams whose kernels each want the whole chip -- *frac = the part
+ * of two probe grids' joint span in which both had workgroups running (about 1: the dispatcher interleaves them; about 0.5: the
+ * second grid's workgroups only start when the first's are all out). */
+int idahip_stream_pair_share(int device, void* streamA, void* streamB, double* frac);
 const char* idahip_last_error(const idahip_ctx* ctx);
 int idahip_sync(idahip_ctx* ctx);
 int idahip_n(const idahip_ctx* ctx);

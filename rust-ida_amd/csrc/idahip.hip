@@ -244,6 +244,47 @@ int idahip_concurrent_streams(int device, int count, void** streams_out, int* nc
     return 0;
 }
 
+// Diagnostic (tools/half_streams.py): how evenly the device shares itself between two streams whose kernels each want all of it.
+// A grid of 2048 workgroups that hold 64 KB of LDS each (two fit a CU: 512 resident) and wait 20 us is launched on A and, right
+// behind it, on B; every workgroup notes its start and end. *frac = the part of the two kernels' joint span in which both had
+// workgroups running: ~1 when the dispatcher interleaves the two grids, ~0.5 when B's workgroups only start once A's are all out.
+__global__ void stream_share_kernel(unsigned long long* out, long long ticks) {
+    extern __shared__ unsigned char pad_lds[];
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) pad_lds[0] = 1;  // (keeps the allocation)
+    while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(16);
+    if (threadIdx.x == 0) {
+        atomicMin(out, t0);
+        atomicMax(out + 1, wall_clock64());
+    }
+}
+
+int idahip_stream_pair_share(int device, void* streamA, void* streamB, double* frac) {
+    if (!streamA || !streamB || !frac) return -2;
+    DevGuard dev_guard__(device);
+    unsigned long long* st = nullptr;
+    if (hipHostMalloc((void**)&st, 4 * sizeof(unsigned long long)) != hipSuccess) return -100;
+    st[0] = st[2] = ~0ull;
+    st[1] = st[3] = 0ull;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stream_share_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stream_share_kernel, dim3(2048), dim3(64), 65536, (hipStream_t)streamA, st, 2000ll);
+    hipLaunchKernelGGL(stream_share_kernel, dim3(2048), dim3(64), 65536, (hipStream_t)streamB, st + 2, 2000ll);
+    int rc = hipGetLastError() == hipSuccess ? 0 : -100;
+    if (hipStreamSynchronize((hipStream_t)streamA) != hipSuccess) rc = -100;
+    if (hipStreamSynchronize((hipStream_t)streamB) != hipSuccess) rc = -100;
+    if (!rc) {
+        const double lo = (double)(st[0] < st[2] ? st[0] : st[2]), hi = (double)(st[1] > st[3] ? st[1] : st[3]);
+        const double olo = (double)(st[0] > st[2] ? st[0] : st[2]), ohi = (double)(st[1] < st[3] ? st[1] : st[3]);
+        *frac = hi > lo ? (ohi > olo ? (ohi - olo) / (hi - lo) : 0.0) : 0.0;
+    }
+    (void)hipHostFree(st);
+    return rc;
+}
+
 int idahip_release_streams(int device, int count, void** streams) {
     if (!streams || count < 0) return -2;
     DevGuard dev_guard__(device);

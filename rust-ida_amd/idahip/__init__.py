@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams", "idahip_stream_pair_share",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
@@ -81,6 +81,7 @@ def load():
     H.idahip_destroy.argtypes = [vp]
     H.idahip_concurrent_streams.argtypes = [ci, ci, C.POINTER(vp), C.POINTER(ci)]
     H.idahip_release_streams.argtypes = [ci, ci, C.POINTER(vp)]
+    H.idahip_stream_pair_share.argtypes = [ci, vp, vp, C.POINTER(cd)]
     H.idahip_last_error.argtypes = [vp]
     H.idahip_last_error.restype = C.c_char_p
     H.idahip_sync.argtypes = [vp]
@@ -638,3 +639,13 @@ def release_streams(streams, device=0):
     H, _ = load()
     arr = (C.c_void_p * len(streams))(*[s.value if isinstance(s, C.c_void_p) else s for s in streams])
     H.idahip_release_streams(int(device), len(streams), arr)
+
+
+def stream_pair_share(a, b, device=0):
+    """idahip_stream_pair_share: the part of two chip-filling probe grids' joint span in which both streams had workgroups running."""
+    H, _ = load()
+    f = C.c_double(0.0)
+    rc = H.idahip_stream_pair_share(int(device), a, b, C.byref(f))
+    if rc != 0:
+        raise IdaHipError("idahip_stream_pair_share failed (%d)" % rc)
+    return f.value

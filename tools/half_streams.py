@@ -61,6 +61,9 @@ def main():
             streams, nconc = [mkstream() for g in range(G)], -1
         else:
             streams, nconc = idahip.concurrent_streams(G)  # probed: really side by side on the device
+        share = [[idahip.stream_pair_share(streams[i], streams[j]) for j in range(G)] for i in range(G)]
+        print("pairwise share of the chip between the streams (1 = interleaved dispatch): " +
+              " | ".join(" ".join("%.2f" % share[i][j] if i != j else "  - " for j in range(G)) for i in range(G)), flush=True)
         groups = [Half(n, per, g * per, stagger, streams[g]) for g in range(G)]
         print("---- %d groups, mutually concurrent streams %d" % (G, nconc), flush=True)
         h = groups[0]
