@@ -448,6 +448,8 @@ def main():
     import idahip
     dev_early = 0 if os.environ.get("IDAHIP_BENCH_REHEARSE") == "1" else local_rank
     gstreams, nconc = (idahip.concurrent_streams(G, dev_early) if G > 1 else ([None], 1))
+    # (diagnostic in the line: the least even share of the chip between two of the groups' streams, 1 = interleaved dispatch)
+    share_min = min([idahip.stream_pair_share(gstreams[i], gstreams[j], dev_early) for i in range(G) for j in range(G) if i != j], default=None)
     if args.workload == "linear_dense":
         # the shard's matrices go from the generator to the device a slice (<= 2 GiB) at a time: the process never holds the
         # 17 GB host copy of its shard (eight ranks of a node would hold 137 GB), only the calibration / CPU-baseline sample
@@ -679,7 +681,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective",
-                       "groups_per_gpu": args.groups, "group_sizes": gsz, "mutually_concurrent_streams": nconc,
+                       "groups_per_gpu": args.groups, "group_sizes": gsz, "mutually_concurrent_streams": nconc, "least_pairwise_stream_share": None if share_min is None else round(share_min, 3),
                        "groups": "the rank's systems run as %d ensemble(s) side by side on the one device, each on its own HIP stream and host "
                                  "thread (idaens_stream_group): every system is integrated exactly as alone; the groups only fill each other's idle "
                                  "stretches of a lock-step round%s" % (args.groups, " -- here they take turns (serial)" if run.serial else "")},
