@@ -1,6 +1,7 @@
-// A whole 64-column super-panel of a matrix with more than 1024 live rows in ONE launch (dense_get_rf,
-// /root/reference/crates/linear/src/dense.rs:86-158, restricted to the super-panel's columns): one workgroup per matrix, R live
-// rows per lane in registers, left-looking over eight blocks of 8 columns.
+// A whole 64-column super-panel of a large matrix (n > 1024: config 4's 4096 x 4096 Jacobians, ~100 matrices per call) in ONE
+// launch (dense_get_rf, /root/reference/crates/linear/src/dense.rs:86-158, restricted to the super-panel's columns): one workgroup
+// per matrix, R live rows per lane in registers (8 above 2048 live rows, 4 above 1024, 2 below), left-looking over eight blocks of
+// 8 columns.
 //
 // Why: until round 4 such a super-panel was 8 launches of lu_panelr_kernel (8 columns each) with a narrow lu_trail_kernel launch
 // after each to carry the panel's update to the rest of the super-panel -- 15 launches, and of a panel launch's 38 us at 4096
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_superpanel_kernel(LuWs w, const 
     double* __restrict__ l11 = w.l11 + (long)b * L11_STRIDE;  // transposed L11 of the super-panel, row length w.l11ld (64)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(A, 0, n * n * 8, 0x00020000);
 
-    const int m = n - k0;      // live rows when the super-panel starts: > 1024, so the super-panel has its 64 columns
+    const int m = n - k0;      // live rows when the super-panel starts: >= 64 (lu_driver.hpp), so the super-panel has its 64 columns
     const int T = blockDim.x;  // R * T >= m
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
