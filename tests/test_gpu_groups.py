@@ -124,4 +124,7 @@ def test_concurrent_streams_are_usable_and_distinct():
     assert (st == 0).all()
     e.close()
     ctx.close()
+    # the streams the probe calls concurrent also share the chip evenly when both want all of it; a stream with itself takes turns
+    assert idahip.stream_pair_share(streams[0], streams[1]) > 0.8 if nconc >= 2 else True
+    assert idahip.stream_pair_share(streams[0], streams[0]) < 0.2
     idahip.release_streams(streams)
