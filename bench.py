@@ -449,7 +449,10 @@ def main():
     dev_early = 0 if os.environ.get("IDAHIP_BENCH_REHEARSE") == "1" else local_rank
     gstreams, nconc = (idahip.concurrent_streams(G, dev_early) if G > 1 else ([None], 1))
     # (diagnostic in the line: the least even share of the chip between two of the groups' streams, 1 = interleaved dispatch)
-    share_min = min([idahip.stream_pair_share(gstreams[i], gstreams[j], dev_early) for i in range(G) for j in range(G) if i != j], default=None)
+    try:
+        share_min = min([idahip.stream_pair_share(gstreams[i], gstreams[j], dev_early) for i in range(G) for j in range(G) if i != j], default=None)
+    except idahip.IdaHipError:  # a diagnostic must not stop the run
+        share_min = None
     if args.workload == "linear_dense":
         # the shard's matrices go from the generator to the device a slice (<= 2 GiB) at a time: the process never holds the
         # 17 GB host copy of its shard (eight ranks of a node would hold 137 GB), only the calibration / CPU-baseline sample
