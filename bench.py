@@ -447,10 +447,13 @@ def main():
     # queue: idahip_concurrent_streams finds that out with a probe kernel); one group: the context's own stream
     import idahip
     dev_early = 0 if os.environ.get("IDAHIP_BENCH_REHEARSE") == "1" else local_rank
-    gstreams, nconc = (idahip.concurrent_streams(G, dev_early) if G > 1 else ([None], 1))
+    try:
+        gstreams, nconc = (idahip.concurrent_streams(G, dev_early) if G > 1 else ([None], 1))
+    except idahip.IdaHipError:  # the probe could not run: ordinary streams (every context creates its own), and the line says so
+        gstreams, nconc = [None] * G, 0
     # (diagnostic in the line: the least even share of the chip between two of the groups' streams, 1 = interleaved dispatch)
     try:
-        share_min = min([idahip.stream_pair_share(gstreams[i], gstreams[j], dev_early) for i in range(G) for j in range(G) if i != j], default=None)
+        share_min = None if nconc == 0 else min([idahip.stream_pair_share(gstreams[i], gstreams[j], dev_early) for i in range(G) for j in range(G) if i != j], default=None)
     except idahip.IdaHipError:  # a diagnostic must not stop the run
         share_min = None
     if args.workload == "linear_dense":
