@@ -250,6 +250,13 @@ int idahip_round_solve(idahip_ctx* ctx, void* hSys, size_t sys_bytes, const idah
  * Any other value is refused. (Round 2's variant 5, the same kernels with FMA-contracted updates, is gone: DESIGN.md.) */
 int idahip_set_lu_variant(idahip_ctx* ctx, int variant);
 int idahip_lu_variant(const idahip_ctx* ctx); /* the variant in force */
+/* Matrices with more than 1024 rows: how a 64-column super-panel is factored. 1 = in one launch of the left-looking
+ * workgroup-per-matrix kernel (lu_superpanel_kernel): the faster pipeline for BANDED matrices in dense storage (config 4's heat
+ * Jacobians: 238 against 322 us per 4096 x 4096 matrix) and the default for IDAHIP_HEAT1D; 0 = eight 8-column panel launches with a
+ * narrow update after each, faster on DENSE matrices (they spread the update over several workgroups per matrix) and the default for
+ * every other problem kind. A hint about structure, never about results: the factors are bit-identical either way. */
+int idahip_set_lu_superpanel(idahip_ctx* ctx, int on);
+int idahip_lu_superpanel(const idahip_ctx* ctx); /* the setting in force */
 /* 0 for the product library. 1 for a TIMING BUILD (-DIDAHIP_TIMING_BUILD, rust-ida_amd/csrc/exp_switches.hpp): a library in
  * which parts of kernels were removed or replaced to measure what they cost -- its results are garbage by design; a caller
  * that cares (tests, bench.py) refuses to run on one. No ctx, no device needed. */

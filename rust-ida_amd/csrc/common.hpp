@@ -67,10 +67,12 @@ struct idahip_ctx {
     double *ic_y = nullptr, *ic_yp = nullptr;  // [batch][n] initial conditions kept for idahip_restore_initial (lazy)
     double* dky = nullptr;                     // [batch][n] result buffer of idahip_get_dky (lazy)
     int lu_variant = 4;  // 4: one wave per matrix factors each 64-column super-panel (lu_wavepanel.hpp, default)
-    // more than 1024 live rows: 1 (default) = a 64-column super-panel is one launch of lu_superpanel_kernel; 0 = round 4's eight
-    // 8-column panel launches with a narrow update after each (IDAHIP_LU_SUPERPANEL=0 at idahip_create: the A/B and the cross-check
-    // in the tests). Bit-identical factors either way.
-    int lu_superpanel = 1;
+    // n > 1024: 1 = a 64-column super-panel is ONE launch of lu_superpanel_kernel (left-looking; made for banded matrices in dense
+    // storage, where it is 26 % faster: config 4), 0 = round 4's eight 8-column panel launches with a narrow update after each,
+    // which spread a dense matrix's update over up to 8 workgroups and stay faster there (dense n = 1536 / 2048 / 4096: 6 / 11 / 48 %).
+    // Default by problem: on for IDAHIP_HEAT1D (tridiagonal content by construction), off otherwise; idahip_set_lu_superpanel
+    // or IDAHIP_LU_SUPERPANEL=0/1 (read at idahip_create) override. Bit-identical factors either way (tests run both).
+    int lu_superpanel = 0;
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)

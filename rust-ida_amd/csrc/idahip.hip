@@ -75,6 +75,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     idahip_ctx* c = new idahip_ctx();
     c->device = device; c->n = n; c->batch = batch; c->kind = kind;
     c->npad16 = (n + 15) & ~15;
+    c->lu_superpanel = kind == IDAHIP_HEAT1D ? 1 : 0;
     if (const char* sp = std::getenv("IDAHIP_LU_SUPERPANEL")) c->lu_superpanel = std::strtol(sp, nullptr, 10) != 0 ? 1 : 0;
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
@@ -1366,6 +1367,12 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
 
 int idahip_lu_variant(const idahip_ctx* c) { return c ? c->lu_variant : -1; }
 int idahip_timing_build(void) { return tb::TIMING_BUILD ? 1 : 0; }
+int idahip_set_lu_superpanel(idahip_ctx* c, int on) {
+    if (!c) return -1;
+    c->lu_superpanel = on != 0 ? 1 : 0;
+    return 0;
+}
+int idahip_lu_superpanel(const idahip_ctx* c) { return c ? c->lu_superpanel : -1; }
 
 // LSolver::get_type / num_iters / res_norm of the dense direct solver (crates/linear/src/dense.rs:30-36, traits.rs:82-90)
 int idahip_ls_type(const idahip_ctx* c) { return c ? IDAHIP_LS_DIRECT : -1; }

@@ -170,32 +170,71 @@ __global__ __launch_bounds__(MAXT, WPE) void lu_superpanel_kernel(LuWs w, const 
             unsigned long long um = lb > 0 ? s_umask : 0ull;
             um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(um >> 32)) << 32) |
                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)um);
+            if constexpr (R <= 4) {
+                // The multipliers of the NEXT pivot row with work are requested before the arithmetic of the current one: on a dense
+                // matrix every pivot has work, and a loop that loads, waits and computes per pivot is one round trip to memory per
+                // pivot -- lb of them per block (a banded matrix has one pivot with work per block and does not care).
+                double lcur[R], lnxt[R];
+                auto load_l = [&](double (&l)[R], const int k) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) l[i] = buf_load_f64(rsrc, (unsigned)r[i] * 8u, (k0 + k) * n * 8);
+                };
+                load_l(lcur, um != 0ull ? __builtin_ctzll(um) : 0);
 #pragma unroll 1
-            for (; um != 0ull; um &= um - 1ull) {
-                const int k = __builtin_ctzll(um);
-                double u[NB];
-                bool uz[NB];
+                for (; um != 0ull; um &= um - 1ull) {
+                    const int k = __builtin_ctzll(um);
+                    const unsigned long long rest = um & (um - 1ull);
+                    load_l(lnxt, rest != 0ull ? __builtin_ctzll(rest) : k);  // (past the last pivot: the same column again, never used)
+                    double u[NB];
+                    bool uz[NB];
 #pragma unroll
-                for (int j = 0; j < NB; j += 2) {
-                    const double2 q = *reinterpret_cast<const double2*>(&s_u[k][j]);
-                    u[j] = opaque_vgpr(q.x);
-                    u[j + 1] = opaque_vgpr(q.y);
-                    uz[j] = u[j] == 0.0;
-                    uz[j + 1] = u[j + 1] == 0.0;
-                }
-                constexpr int RH = R <= 4 ? R : (R % 4 == 0) ? 4 : (R % 3 == 0) ? 3 : (R % 2 == 0) ? 2 : 1;  // rows per pass (divides R): at most four multipliers in flight
-                static_assert(R % RH == 0, "the passes cover the lane's rows exactly");
+                    for (int j = 0; j < NB; j += 2) {
+                        const double2 q = *reinterpret_cast<const double2*>(&s_u[k][j]);
+                        u[j] = opaque_vgpr(q.x);
+                        u[j + 1] = opaque_vgpr(q.y);
+                        uz[j] = u[j] == 0.0;
+                        uz[j + 1] = u[j + 1] == 0.0;
+                    }
 #pragma unroll
-                for (int i0 = 0; i0 < R; i0 += RH) {
-                    double l[RH];
-#pragma unroll
-                    for (int i = 0; i < RH; ++i) l[i] = buf_load_f64(rsrc, (unsigned)r[i0 + i] * 8u, (k0 + k) * n * 8);
-#pragma unroll
-                    for (int i = 0; i < RH; ++i) {
+                    for (int i = 0; i < R; ++i) {
 #pragma unroll
                         for (int j = 0; j < NB; ++j) {
-                            const double tn = a[i0 + i][j] - u[j] * l[i];
-                            a[i0 + i][j] = (is_alive(i0 + i) && !uz[j]) ? tn : a[i0 + i][j];  // dense.rs:148-151
+                            const double tn = a[i][j] - u[j] * lcur[i];
+                            a[i][j] = (is_alive(i) && !uz[j]) ? tn : a[i][j];  // dense.rs:148-151
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < R; ++i) lcur[i] = lnxt[i];
+                }
+            } else {
+                // eight rows per lane: no registers to spare for a second set of multipliers (it spilled); four at a time
+#pragma unroll 1
+                for (; um != 0ull; um &= um - 1ull) {
+                    const int k = __builtin_ctzll(um);
+                    double u[NB];
+                    bool uz[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; j += 2) {
+                        const double2 q = *reinterpret_cast<const double2*>(&s_u[k][j]);
+                        u[j] = opaque_vgpr(q.x);
+                        u[j + 1] = opaque_vgpr(q.y);
+                        uz[j] = u[j] == 0.0;
+                        uz[j + 1] = u[j + 1] == 0.0;
+                    }
+                    constexpr int RH = 4;
+                    static_assert(R % RH == 0, "the passes cover the lane's rows exactly");
+#pragma unroll
+                    for (int i0 = 0; i0 < R; i0 += RH) {
+                        double l[RH];
+#pragma unroll
+                        for (int i = 0; i < RH; ++i) l[i] = buf_load_f64(rsrc, (unsigned)r[i0 + i] * 8u, (k0 + k) * n * 8);
+#pragma unroll
+                        for (int i = 0; i < RH; ++i) {
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) {
+                                const double tn = a[i0 + i][j] - u[j] * l[i];
+                                a[i0 + i][j] = (is_alive(i0 + i) && !uz[j]) ? tn : a[i0 + i][j];  // dense.rs:148-151
+                            }
                         }
                     }
                 }

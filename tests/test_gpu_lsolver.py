@@ -200,6 +200,41 @@ def test_banded_and_partly_banded_matrices_beyond_1024_rows(n, large_n_pipeline)
     assert np.array_equal(ctx.to_host(dX, (B, n)), x_o)
 
 
+def test_large_n_pipeline_defaults_and_setter(monkeypatch):
+    """The structure hint of include/ida_hip.h: a super-panel per launch is the default for the heat problem (banded Jacobians),
+    panel by panel for every other kind (dense matrices); idahip_set_lu_superpanel switches a context over, and the factors do not
+    depend on it."""
+    import idahip
+    monkeypatch.delenv("IDAHIP_LU_SUPERPANEL", raising=False)
+    h = idahip.Ctx("heat1d", 1100, 2)
+    assert h.lu_superpanel() == 1
+    h.close()
+    n = 1100
+    rng = np.random.default_rng(5)
+    m = np.zeros((2, n, n))
+    i = np.arange(n)
+    for s in range(2):
+        m[s, i, i] = 3.0 + rng.random(n)
+        m[s, i[1:], i[:-1]] = -1.0 - rng.random(n - 1)
+        m[s, i[:-1], i[1:]] = -1.0 - rng.random(n - 1)
+    m[1] += np.where(rng.random((n, n)) < 0.01, rng.standard_normal((n, n)), 0.0)  # a band with some scattered entries
+    res = []
+    for on in (0, 1):
+        ctx = idahip.Ctx("linear_dense", n, 2)
+        assert ctx.lu_superpanel() == 0
+        ctx.set_lu_superpanel(on)
+        assert ctx.lu_superpanel() == on
+        dA = ctx.dev_array(colmajor(m))
+        dP = ctx.dev_empty(8 * 2 * n)
+        rc, info = ctx.ls_setup(dA, dP, None)
+        assert rc == 0 and not info.any()
+        res.append((ctx.to_host(dA, (2, n, n)), ctx.to_host(dP, (2, n), dtype=np.int64)))
+        ctx.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    info_o, lu_o, piv_o = oracle_lu(m)
+    assert np.array_equal(np.transpose(res[1][0], (0, 2, 1)), lu_o) and np.array_equal(res[1][1], piv_o)
+
+
 def test_solve_through_the_buffer_loads_with_a_partial_last_block_at_large_n():
     """wg_getrs with 256 threads reads the diagonal blocks through a buffer descriptor with 32-bit byte counts and scalar
     offsets (n * n * 8 and (kb + k) * n * 8: exact up to n = 4096) and prefetches column groups past the end of a partial last
