@@ -47,7 +47,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 VALU_FMA_TFLOPS = 78.6       # fp64 vector peak with FMA = 1/2 x 157.3 TFLOP/s fp32 vector (same guide), 2.4 GHz
 VALU_UNFUSED_TFLOPS = 39.3   # a multiply and a subtract per update (the reference's arithmetic, dense.rs:151): half of it
-PMC_SUMMARY = os.path.join("profiles", "r04_bench_summary.json")  # committed rocprofv3 --pmc passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r05_bench_summary.json")  # committed rocprofv3 --pmc passes of this command
 
 
 def algorithmic_bytes(n, workload="linear_dense"):
