@@ -12,5 +12,5 @@ d = collections.OrderedDict()
 for r in csv.DictReader(open(p)):
     d.setdefault(r["Kernel_Name"][:70], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in d.items():
-    if any(s in k for s in ("trail", "wavepanel", "finalize", "panel")):
+    if any(s in k for s in ("trail", "wavepanel", "finalize", "panel", "u12", "update16")):
         print("%-72s n=%4d  last: %s  sum(last)=%.0f" % (k, len(v), " ".join("%.0f" % x for x in v[-n:]), sum(v[-n:])))

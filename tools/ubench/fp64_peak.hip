@@ -2,6 +2,7 @@
 //   mode 0: fused multiply-add      acc[i] = fma(-a, acc[i+8], acc[i])
 //   mode 1: multiply then subtract  p = a * acc[i+8]; acc[i] = acc[i] - p   (the reference's arithmetic, -ffp-contract=off)
 //   mode 2: the same with the 16 products computed first and the 16 subtractions after them
+//   mode 3: mode 1 with the common factor in an SGPR pair (v_mul_f64 v, s, v): the operand form of lu_wavepanel_kernel's U entries
 // build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o fp64_peak fp64_peak.hip ; run: ./fp64_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,7 +11,11 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k(double* out, const double* in, int iters) {
     double acc[16];
-    const double a = in[threadIdx.x & 7];
+    double a = in[threadIdx.x & 7];
+    if (MODE == 3) {  // wave-uniform, in SGPRs
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(a)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(a));
+        a = __hiloint2double(hi, lo);
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         acc[i] = in[(threadIdx.x + i) & 63];
@@ -22,7 +27,7 @@ __global__ __launch_bounds__(256) void k(double* out, const double* in, int iter
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(-a, acc[(i + 8) & 15], acc[i]);
-            } else if (MODE == 1) {
+            } else if (MODE == 1 || MODE == 3) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = acc[i] - a * acc[(i + 8) & 15];
             } else {
@@ -79,6 +84,7 @@ int main() {
         run<0>(w, cus, out, in);
         run<1>(w, cus, out, in);
         run<2>(w, cus, out, in);
+        run<3>(w, cus, out, in);
     }
     return 0;
 }
