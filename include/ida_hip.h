@@ -257,12 +257,6 @@ int idahip_lu_variant(const idahip_ctx* ctx); /* the variant in force */
  * every other problem kind. A hint about structure, never about results: the factors are bit-identical either way. */
 int idahip_set_lu_superpanel(idahip_ctx* ctx, int on);
 int idahip_lu_superpanel(const idahip_ctx* ctx); /* the setting in force */
-/* Matrices of 65 to 1024 rows: the rank-64 trailing update of dense_get_rf (dense.rs:139-155) as one kernel per super-panel
- * (0: U12 solve and update in the same workgroup, LDS-tiled) or as two (1: the U12 solve, then an update that holds a live row per
- * lane in registers and takes the U entries as scalar operands -- no LDS, five waves per SIMD; rust-ida_amd/csrc/lu_split.hpp).
- * IDAHIP_LU_SPLIT=0/1 (read by idahip_create) sets the initial value. Never a question of results: bit-identical factors. */
-int idahip_set_lu_split(idahip_ctx* ctx, int on);
-int idahip_lu_split(const idahip_ctx* ctx); /* the setting in force */
 /* 0 for the product library. 1 for a TIMING BUILD (-DIDAHIP_TIMING_BUILD, rust-ida_amd/csrc/exp_switches.hpp): a library in
  * which parts of kernels were removed or replaced to measure what they cost -- its results are garbage by design; a caller
  * that cares (tests, bench.py) refuses to run on one. No ctx, no device needed. */

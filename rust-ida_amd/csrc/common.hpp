@@ -73,11 +73,6 @@ struct idahip_ctx {
     // Default by problem: on for IDAHIP_HEAT1D (tridiagonal content by construction), off otherwise; idahip_set_lu_superpanel
     // or IDAHIP_LU_SUPERPANEL=0/1 (read at idahip_create) override. Bit-identical factors either way (tests run both).
     int lu_superpanel = 0;
-    // n <= 1024: 1 = the rank-64 trailing update as two kernels (lu_split.hpp: U12 solve, then an update without LDS whose U operands
-    // are scalar loads), 0 = lu_trail64w_kernel does both. idahip_set_lu_split or IDAHIP_LU_SPLIT=0/1. Bit-identical factors.
-    int lu_split = 0;
-    double* lu_u12 = nullptr;   // [batch][16][64*64] with lu_split (lazy)
-    int32_t* lu_u12f = nullptr; // [batch][16]
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)

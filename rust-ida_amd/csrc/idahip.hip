@@ -77,7 +77,6 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     c->npad16 = (n + 15) & ~15;
     c->lu_superpanel = kind == IDAHIP_HEAT1D ? 1 : 0;
     if (const char* sp = std::getenv("IDAHIP_LU_SUPERPANEL")) c->lu_superpanel = std::strtol(sp, nullptr, 10) != 0 ? 1 : 0;
-    if (const char* sp = std::getenv("IDAHIP_LU_SPLIT")) c->lu_split = std::strtol(sp, nullptr, 10) != 0 ? 1 : 0;
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
@@ -140,7 +139,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (!c) return 0;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_l11, c->lu_u12, c->lu_u12f, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
                     c->tiny_acc, c->tiny_roots, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
@@ -1374,12 +1373,6 @@ int idahip_set_lu_superpanel(idahip_ctx* c, int on) {
     return 0;
 }
 int idahip_lu_superpanel(const idahip_ctx* c) { return c ? c->lu_superpanel : -1; }
-int idahip_set_lu_split(idahip_ctx* c, int on) {
-    if (!c) return -1;
-    c->lu_split = on != 0 ? 1 : 0;
-    return 0;
-}
-int idahip_lu_split(const idahip_ctx* c) { return c ? c->lu_split : -1; }
 
 // LSolver::get_type / num_iters / res_norm of the dense direct solver (crates/linear/src/dense.rs:30-36, traits.rs:82-90)
 int idahip_ls_type(const idahip_ctx* c) { return c ? IDAHIP_LS_DIRECT : -1; }

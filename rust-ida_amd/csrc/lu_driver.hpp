@@ -3,7 +3,6 @@
 #include "lu_kernels.hpp"
 #include "lu_wavepanel.hpp"
 #include "lu_superpanel.hpp"
-#include "lu_split.hpp"
 
 namespace idahip {
 
@@ -31,15 +30,6 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;
     w.zmap = (out == c->lu) ? c->lu_zmap : nullptr;  // the map describes the ctx's own factors (the Newton iteration's solves)
     w.l11 = c->lu_l11; w.stamps = c->dbg_stamps; w.out = out; w.ostride = ostride; w.l11ld = 64;
-    w.u12 = nullptr; w.u12f = nullptr;
-    if (c->lu_split && n <= LU_MAX_N && n > 64) {
-        if (!c->lu_u12) {
-            if (hipMalloc((void**)&c->lu_u12, (size_t)c->batch * U12_BLOCKS * U12_STRIDE * sizeof(double)) != hipSuccess ||
-                hipMalloc((void**)&c->lu_u12f, (size_t)c->batch * U12_BLOCKS * sizeof(int)) != hipSuccess)
-                return fail(c, -100, "no memory for the U12 blocks of the two-kernel trailing update");
-        }
-        w.u12 = c->lu_u12; w.u12f = c->lu_u12f;
-    }
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;
     constexpr int NB = LU_NB;
@@ -153,12 +143,6 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
                 // kernel at full occupancy; the update kernel's workgroups for them leave at once
                 hipLaunchKernelGGL(lu_u12_zero_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_BIG_MAX_N>, dim3(nsys8 * (ncb + (nsplit - 1) * nbs)), dim3(256), 0, c->stream, w, k0, nsys, ncb, nsplit);
-            } else if (w.u12) {
-                // two kernels (lu_split.hpp): the U12 solve, then the update with scalar U operands; between them the one-kernel
-                // form for the blocks the solve has flagged (an exact zero among the pivot-row entries: none in a dense batch)
-                hipLaunchKernelGGL(lu_u12_kernel, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb);
-                hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, -1);
-                hipLaunchKernelGGL(lu_update16_kernel<8>, dim3(nsys8 * ncb * ((ntrail + 63) / 64)), dim3(256), 0, c->stream, w, k0, nsys, ncb, (ntrail + 63) / 64);
             } else
                 hipLaunchKernelGGL(lu_trail64w_kernel<LU_MAX_N>, dim3(nsys8 * ncb), dim3(256), 0, c->stream, w, k0, nsys, ncb, 1);
         }

@@ -54,8 +54,6 @@ struct LuWs {
     unsigned long long* stamps;  // timing builds (-DIDAHIP_STAMPS): time stamps of one launch, null otherwise
     double* out;       // factors in the reference layout (rows at their pivoted positions), column-major n x n
     long ostride;      // elements between consecutive systems in out
-    double* u12;       // null, or [batch][16][64][64] (lu_split.hpp, n <= 1024): U12 of each column block of the current super-panel's update, row k = 64 consecutive doubles
-    int* u12f;         // [batch][16] with u12: 1 = lu_u12_kernel has solved the block, 2 = it met an exact zero (the block is lu_trail64w_kernel's)
 };
 constexpr int L11_STRIDE = 64 * 64;  // elements per system in LuWs::l11
 
@@ -918,8 +916,6 @@ __global__ __launch_bounds__(256, MAXROWS <= 1024 ? 3 : 2) void lu_trail64w_kern
     if (mi >= (w.cnt ? ldc(w.cnt) : nsys)) return;
     const int b = w.idx[mi];
     if (w.info[b] != 0) return;
-    // n <= 1024 with the two-kernel update (lu_split.hpp; nsplit_arg < 0): only the blocks lu_u12_kernel has flagged
-    if (MAXROWS <= 1024 && nsplit_arg < 0 && ldc(w.u12f + (long)b * 16 + cbi) != 2) return;
     // nsplit > 1: the strips of live rows of one (matrix, column block) are dealt to nsplit workgroups when the matrix has
     // shown itself banded -- at most a quarter of the column blocks of the first super-panel's update (k0 == 0, counted in
     // nzb by lu_u12_zero_kernel) had a non-zero pivot-row entry -- and the block is one of the first few, next to the panel, where a band has its

@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams", "idahip_stream_pair_share", "idahip_set_lu_superpanel", "idahip_lu_superpanel", "idahip_set_lu_split", "idahip_lu_split",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams", "idahip_stream_pair_share", "idahip_set_lu_superpanel", "idahip_lu_superpanel",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
@@ -84,8 +84,6 @@ def load():
     H.idahip_stream_pair_share.argtypes = [ci, vp, vp, C.POINTER(cd)]
     H.idahip_set_lu_superpanel.argtypes = [vp, ci]
     H.idahip_lu_superpanel.argtypes = [vp]
-    H.idahip_set_lu_split.argtypes = [vp, ci]
-    H.idahip_lu_split.argtypes = [vp]
     H.idahip_last_error.argtypes = [vp]
     H.idahip_last_error.restype = C.c_char_p
     H.idahip_sync.argtypes = [vp]
@@ -407,13 +405,6 @@ class Ctx:
 
     def lu_superpanel(self):
         return int(self.H.idahip_lu_superpanel(self.h))
-
-    def set_lu_split(self, on):
-        """65 <= n <= 1024: the rank-64 trailing update as two kernels (U12 solve; register / scalar-operand update) or as one."""
-        self._chk(self.H.idahip_set_lu_split(self.h, int(on)), "set_lu_split")
-
-    def lu_split(self):
-        return int(self.H.idahip_lu_split(self.h))
 
     def set_lu_variant(self, variant):
         self._chk(self.H.idahip_set_lu_variant(self.h, int(variant)), "set_lu_variant")

@@ -19,15 +19,13 @@ def colmajor(mats):
 
 
 LU_VARIANT = 4
-LU_SPLIT = 0
 
 
-@pytest.fixture(params=[(3, 0), (4, 0), (4, 1)], ids=["lu-panel2", "lu-wavepanel", "lu-wavepanel-split-update"], autouse=True)
+@pytest.fixture(params=[3, 4], ids=["lu-panel2", "lu-wavepanel"], autouse=True)
 def lu_variant(request):
-    """Every test of this file runs against every factorisation pipeline: the two panel pipelines, and the wave-per-matrix one
-    with the rank-64 trailing update as two kernels (csrc/lu_split.hpp: U12 solve, register / scalar-operand update)."""
-    global LU_VARIANT, LU_SPLIT
-    LU_VARIANT, LU_SPLIT = request.param
+    """Every test of this file runs against every factorisation pipeline."""
+    global LU_VARIANT
+    LU_VARIANT = request.param
     yield
 
 
@@ -36,8 +34,6 @@ def gpu_lu(mats, idx=None):
     B, n, _ = mats.shape
     ctx = idahip.Ctx("linear_dense" if n != 3 else "lorenz63", n, B)
     ctx.set_lu_variant(LU_VARIANT)
-    ctx.set_lu_split(LU_SPLIT)
-    assert ctx.lu_split() == LU_SPLIT
     dA = ctx.dev_array(colmajor(mats))
     dP = ctx.dev_empty(8 * B * n)
     rc, info = ctx.ls_setup(dA, dP, idx)
@@ -365,8 +361,6 @@ def test_empty_and_invalid_system_lists():
     mats = rng.standard_normal((B, n, n))
     ctx = idahip.Ctx("linear_dense", n, B)
     ctx.set_lu_variant(LU_VARIANT)
-    ctx.set_lu_split(LU_SPLIT)
-    assert ctx.lu_split() == LU_SPLIT
     dA = ctx.dev_array(colmajor(mats))
     dP = ctx.dev_empty(8 * B * n)
     before = ctx.to_host(dA, (B, n, n)).copy()
