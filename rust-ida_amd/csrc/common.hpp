@@ -40,6 +40,7 @@ struct idahip_ctx {
     int n = 0;
     int batch = 0;
     int npad16 = 0;  // n rounded up to a multiple of 16 (Ubuf row stride)
+    int simds = 0;   // SIMDs of the device (4 per CU): idahip_tiny_solve sizes its wavefronts by it
     idahip_problem kind = IDAHIP_ROBERTS;
     hipStream_t stream = nullptr;
     bool own_stream = false;

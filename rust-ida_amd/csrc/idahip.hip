@@ -81,6 +81,10 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
     if (hipSetDevice(device) != hipSuccess) { delete c; return -100; }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->simds = 4 * cus;
+    }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -1155,16 +1159,31 @@ int idahip_tiny_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip_
     a.rounds_done = (long long*)c->tiny_rounds;
     {
         KTimer kt(c, IDAHIP_K_VECTOR, batch);
-        // LDS: the 64 controller records of a workgroup, and the systems' vectors too when the device grants that much
-        const size_t lds_state = 64 * sizeof(idactl::SysCore), lds_all = lds_state + 64 * sizeof(double) * tiny_lds_doubles(n);
+        // Systems per wavefront. A lane walks one system's dependent fp64 chains, and the lanes of a wavefront, each in another phase
+        // of its step (one, two or four Newton iterations, a failed error test, an order change, an output), execute each
+        // other's branches. A batch that does not fill the device therefore runs on more, narrower wavefronts: the fewest
+        // systems per wavefront (64, 32, ... 1) that keep the wavefront count at or below one per CU. Config 2 (1024 systems,
+        // same box): 64 per wavefront 57.3 M Newton iterations/s in the stream (67.1 M whole pass), 16: 63.1 (70.5), 4: 70.9 (75.8),
+        // 1: 65.6 (67.5). IDAHIP_TINY_SPW overrides (measurements). The per-system program is the same: results do not depend on it.
+        int spw = 64;
+        {
+            const int simds = c->simds > 0 ? c->simds : 1024;
+            while (spw > 1 && (long)(batch + spw / 2 - 1) / (spw / 2) <= simds / 4) spw >>= 1;
+            if (const char* e = std::getenv("IDAHIP_TINY_SPW")) {
+                const int v = (int)std::strtol(e, nullptr, 10);
+                if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) spw = v;
+            }
+        }
+        // LDS: the controller records of a workgroup, and the systems' vectors too when the device grants that much
+        const size_t lds_state = (size_t)spw * sizeof(idactl::SysCore), lds_all = lds_state + (size_t)spw * sizeof(double) * tiny_lds_doubles(n);
         // four instantiations: problem x (root finding compiled in | out -- the bracketing code costs the plain stepper registers)
         const bool roots = call->nroots > 0;
         auto kern = c->kind == IDAHIP_ROBERTS ? (roots ? tiny_ida_kernel<IDAHIP_ROBERTS, true> : tiny_ida_kernel<IDAHIP_ROBERTS, false>)
                                               : (roots ? tiny_ida_kernel<IDAHIP_LORENZ63, true> : tiny_ida_kernel<IDAHIP_LORENZ63, false>);
-        const int lds_vec = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) == hipSuccess ? 1 : 0;
+        const int lds_vec = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * (sizeof(idactl::SysCore) + sizeof(double) * tiny_lds_doubles(n)))) == hipSuccess ? 1 : 0;
         if (!lds_vec) (void)hipGetLastError();
         const size_t shm = lds_vec ? lds_all : lds_state;
-        hipLaunchKernelGGL(kern, dim3((batch + 63) / 64), dim3(64), shm, c->stream, a, lds_vec);
+        hipLaunchKernelGGL(kern, dim3((batch + spw - 1) / spw), dim3(spw), shm, c->stream, a, lds_vec);
         if ((rc = post_launch(c, "tiny_ida"))) return rc;
     }
     IDAHIP_HIP(c, hipMemcpyAsync(hSys, c->tiny_sys, (size_t)batch * sizeof(idactl::SysCore), hipMemcpyDeviceToHost, c->stream));

@@ -306,12 +306,13 @@ __global__ __launch_bounds__(64) void tiny_ida_kernel(TinyIdaArgs ga, int lds_ve
     extern __shared__ __align__(16) unsigned char tiny_sm[];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= ga.f.batch) return;
+    // (blockDim.x = systems per wavefront, 64 or fewer: idahip_tiny_solve picks it by the batch size)
     idactl::SysCore& s = *reinterpret_cast<idactl::SysCore*>(tiny_sm + threadIdx.x * sizeof(idactl::SysCore));
     s = ga.sys[b];
     TinyIdaArgs a = ga;
     constexpr int n = 3;  // Roberts and Lorenz63 (idahip_create insists): a constant lets every vector loop unroll into registers
     const long gvb = (long)b * n;
-    double* blk = reinterpret_cast<double*>(tiny_sm + 64 * sizeof(idactl::SysCore)) + (long)threadIdx.x * tiny_lds_doubles(n);
+    double* blk = reinterpret_cast<double*>(tiny_sm + blockDim.x * sizeof(idactl::SysCore)) + (long)threadIdx.x * tiny_lds_doubles(n);
     if (lds_vec) {
         for (int j = 0; j < MXORDP1; ++j)
             for (int i = 0; i < n; ++i) blk[j * n + i] = ga.v.phi[j * ga.v.phistride + gvb + i];
