@@ -60,6 +60,25 @@ def test_sampled_systems_match_the_oracle_bit_for_bit(full):
     assert np.array_equal(full["yp"][SAMPLE], ref["yp"][-1])
 
 
+def test_every_system_of_the_batch_matches_the_oracle_bit_for_bit(full):
+    """Exhaustive, not sampled: the oracle integrates ALL 4096 systems of config 3 over the whole horizon on the box's host
+    cores (one std::thread per core, about 40 s on 64 cores) and every system's final state, last step size and order and
+    every counter must equal the device's. (On a box with fewer than 32 cores: the first 512 systems.)"""
+    ncpu = os.cpu_count() or 1
+    count = B if ncpu >= 32 else 512
+    prob = full["prob"]
+    ref = O.run_ensemble("linear_dense", N, prob["yy0"][:count], prob["yp0"][:count], prob["rtol"], prob["atol"], full["touts"],
+                         A=prob["A"][:count], B=prob["B"][:count], c=prob["c"][:count], nthreads=min(ncpu, 64))
+    assert (ref["status"] == 0).all()
+    for k in CNT:
+        assert np.array_equal(full["counters"][k][:count], ref["counters"][k]), k
+    assert np.array_equal(full["counters"]["kused"][:count], ref["kused"])
+    assert np.array_equal(full["hused"][:count], ref["hused"])
+    assert np.array_equal(full["yy"][:count], ref["yy"][-1])
+    assert np.array_equal(full["yp"][:count], ref["yp"][-1])
+    print("oracle: %d systems in %.1f s on %d threads" % (count, ref["seconds"], min(ncpu, 64)))
+
+
 QUIRK_PATHS = ("ncfn", "nlufail", "nconv_jcur", "nfail_first")
 
 
