@@ -151,6 +151,7 @@ class Runner:
     (Ida::new from its initial conditions) and starts over at once. The batch never drains: every lock-step round works on
     every system, each somewhere else in its integration."""
 
+    LU_PERIOD = 1   # idahip_set_lu_period of every context (set from --lu-period)
     STAGGER = None  # rounds over which the systems' first starts are spread; None: one typical integration (calibrated)
     SPIN_UP = 200   # untimed rounds before the warm-up: the stagger plus at least one more integration
     CALIBRATION_SYSTEMS = 128
@@ -187,6 +188,9 @@ class Runner:
         self.serial = serial
         self.stagger = self.STAGGER if self.STAGGER is not None else self.integration_length(probs[0], device, self.CALIBRATION_SYSTEMS)
         self.ctxs = ctxs if ctxs is not None else [problems.make_ctx(p, device=device) for p in probs]
+        if self.LU_PERIOD > 1 and self.probs[0].get("kind") not in ("lorenz63", "roberts"):
+            for c in self.ctxs:
+                c.set_lu_period(self.LU_PERIOD)
         self.enss = [idahip.Ensemble(c, p["yy0"], p["yp0"]) for c, p in zip(self.ctxs, probs)]
         self.steppers = [e.device_controller_active() for e in self.enss]
         if TIME_ALL:
@@ -369,6 +373,9 @@ def launch_ranks(n):
 # ensembles per GPU by default: same-box A/Bs in DESIGN.md section 4b (tools/half_streams.py); the one-thread-per-system stepper
 # of the n = 3 problems runs whole schedules in one launch and has nothing to interleave
 DEFAULT_GROUPS = {"linear_dense": 4, "heat1d": 1, "lorenz63": 1}
+# linear setups only in every k-th lock-step round (idahip_set_lu_period; systems that need one wait, results unchanged): pays where a
+# batched factorisation costs about the same for 50 matrices as for 250 (config 4), costs where its time is proportional to the batch
+DEFAULT_LU_PERIOD = {"linear_dense": 2, "heat1d": 5, "lorenz63": 1}
 
 
 WORKLOADS = {
@@ -399,6 +406,8 @@ def main():
     ap.add_argument("--groups", type=int, default=None,
                     help="ensembles per GPU, each with 1/groups of the rank's systems on its own HIP stream and host thread "
                          "(idaens_stream_group; default: %s)" % ", ".join("%s %d" % kv for kv in DEFAULT_GROUPS.items()))
+    ap.add_argument("--lu-period", type=int, default=None, help="linear setups only in every k-th round of the device lock-step stepper "
+                    "(default: %s)" % ", ".join("%s %d" % kv for kv in DEFAULT_LU_PERIOD.items()))
     ap.add_argument("--passes", type=int, default=10, help="whole passes timed for `whole_pass` (SURVEY 8(d): >= 10 repetitions on fresh state, median)")
     ap.add_argument("--results-npz", default=None,
                     help="rank 0 writes the concatenated per-system results of the ensemble's verification pass (nst, nni, y(tout), y'(tout) in "
@@ -411,6 +420,8 @@ def main():
     args.n = dn if args.n is None else args.n
     args.batch = db if args.batch is None else args.batch
     args.groups = DEFAULT_GROUPS[args.workload] if args.groups is None else args.groups
+    args.lu_period = DEFAULT_LU_PERIOD[args.workload] if args.lu_period is None else args.lu_period
+    Runner.LU_PERIOD = args.lu_period
     args.groups = max(1, min(args.groups, args.batch))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -687,6 +698,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl % (args.n, args.batch), "n": args.n, "batch_per_gpu": args.batch, "total_batch": args.batch * world,
                        "sharding": "independent systems, contiguous block per rank, no collective",
+                       "lu_period": args.lu_period,
                        "groups_per_gpu": args.groups, "group_sizes": gsz, "mutually_concurrent_streams": nconc, "least_pairwise_stream_share": None if share_min is None else round(share_min, 3),
                        "groups": "the rank's systems run as %d ensemble(s) side by side on the one device, each on its own HIP stream and host "
                                  "thread (idaens_stream_group): every system is integrated exactly as alone; the groups only fill each other's idle "

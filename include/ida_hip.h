@@ -257,6 +257,16 @@ int idahip_lu_variant(const idahip_ctx* ctx); /* the variant in force */
  * every other problem kind. A hint about structure, never about results: the factors are bit-identical either way. */
 int idahip_set_lu_superpanel(idahip_ctx* ctx, int on);
 int idahip_lu_superpanel(const idahip_ctx* ctx); /* the setting in force */
+/* Device lock-step stepper (idahip_round_solve): linear setups -- Jacobian + dense_get_rf, ida_ls.rs:232-290 -- batched over rounds.
+ * With rounds = k > 1 a lock-step round sets nothing up unless at least (k - 1) / k of the systems that are stepping ask for a setup
+ * (lib.rs:806-817) or k - 1 rounds in a row have waited already; a system that asks waits, its attempt begun, while the others go
+ * on stepping, and a round without setups launches no factorisation at all. 1 = every round serves its setups (the default); at
+ * most 64. A scheduling choice: every system performs the same attempts with the same arithmetic, so its results and counters do not
+ * change (tests/test_gpu_device_controller.py). It pays where a batched factorisation costs about the same for 50 matrices as for
+ * 250 -- matrices of thousands of rows, a workgroup per matrix and a long chain of launches (config 4) -- and costs throughput where
+ * the factorisation's time is proportional to the batch (config 3). */
+int idahip_set_lu_period(idahip_ctx* ctx, int rounds);
+int idahip_lu_period(const idahip_ctx* ctx); /* the setting in force */
 /* 0 for the product library. 1 for a TIMING BUILD (-DIDAHIP_TIMING_BUILD, rust-ida_amd/csrc/exp_switches.hpp): a library in
  * which parts of kernels were removed or replaced to measure what they cost -- its results are garbage by design; a caller
  * that cares (tests, bench.py) refuses to run on one. No ctx, no device needed. */

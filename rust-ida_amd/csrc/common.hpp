@@ -74,6 +74,10 @@ struct idahip_ctx {
     // Default by problem: on for IDAHIP_HEAT1D (tridiagonal content by construction), off otherwise; idahip_set_lu_superpanel
     // or IDAHIP_LU_SUPERPANEL=0/1 (read at idahip_create) override. Bit-identical factors either way (tests run both).
     int lu_superpanel = 0;
+    // device lock-step stepper: linear setups batched over rounds (round_lists_kernel): with k > 1 a round postpones its setups unless
+    // (k - 1) / k of the stepping systems ask for one, at most k - 1 rounds in a row. Pays where a factorisation's cost hardly depends
+    // on the number of matrices (n > 1024: one workgroup per matrix, a chain of launches): idahip_set_lu_period / IDAHIP_LU_PERIOD.
+    int lu_period = 1;
                          // 3: panel kernels with two rows per lane + narrow update (lu_kernels.hpp): cross-check, and n > 512
 
     // device-resident stepper for small systems (tiny_ida.hpp): controller states and per-call buffers (lazy)

@@ -77,6 +77,10 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     c->npad16 = (n + 15) & ~15;
     c->lu_superpanel = kind == IDAHIP_HEAT1D ? 1 : 0;
     if (const char* sp = std::getenv("IDAHIP_LU_SUPERPANEL")) c->lu_superpanel = std::strtol(sp, nullptr, 10) != 0 ? 1 : 0;
+    if (const char* sp = std::getenv("IDAHIP_LU_PERIOD")) {
+        const int v = (int)std::strtol(sp, nullptr, 10);
+        if (v >= 1 && v <= 64) c->lu_period = v;
+    }
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return -100; }
     DevGuard dev_guard__(device);  // allocations, stream and events below belong to `device`; the caller's device is restored
@@ -1251,7 +1255,7 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     const long nn = (long)n * n;
     int rc = stepper_buffers(c, call, hYout || hYPout);
     if (rc) return rc;
-    if (!c->rnd_i) rc |= dalloc(c, &c->rnd_i, (size_t)8 * batch + 6 + 2 * IDAHIP_K_COUNT);
+    if (!c->rnd_i) rc |= dalloc(c, &c->rnd_i, (size_t)8 * batch + 8 + 2 * IDAHIP_K_COUNT);
     if (!c->rnd_d) rc |= dalloc(c, &c->rnd_d, (size_t)4 * batch);
     if (rc) return rc;
     if (!c->rnd_host) IDAHIP_HIP(c, hipHostMalloc((void**)&c->rnd_host, 4 * sizeof(int32_t)));
@@ -1270,10 +1274,11 @@ int idahip_round_solve(idahip_ctx* c, void* hSys, size_t sys_bytes, const idahip
     a.ypout = hYPout ? c->tiny_ypout : nullptr;
     a.round_base = call->round_base;
     a.fused_jac = c->kind == IDAHIP_LINEAR_DENSE ? 1 : 0;
+    a.lu_period = c->lu_period;
     a.roots = (idahip_root_state*)c->tiny_roots;
     int* ib = c->rnd_i;
     a.stepping = ib; a.in_newton = ib + batch; a.skipP = ib + 2 * batch; a.skipL = ib + 3 * batch; a.skipI = ib + 4 * batch;
-    a.skipS = ib + 5 * batch; a.ident = ib + 6 * batch; a.lu_list = ib + 7 * batch; a.lu_cnt = ib + 8 * batch; a.summary = ib + 8 * batch + 1;
+    a.skipS = ib + 5 * batch; a.ident = ib + 6 * batch; a.lu_list = ib + 7 * batch; a.lu_cnt = ib + 8 * batch; a.summary = ib + 8 * batch + 1; a.lu_wait = ib + 8 * batch + 3;
     a.stats = (unsigned long long*)(ib + 8 * batch + 4);  // (8 * batch + 4 ints: 8-byte aligned for even batch; checked below)
     if (((uintptr_t)a.stats & 7) != 0) a.stats = (unsigned long long*)(ib + 8 * batch + 5);
     IDAHIP_HIP(c, hipMemsetAsync(a.stats, 0, IDAHIP_K_COUNT * sizeof(unsigned long long), c->stream));
@@ -1392,6 +1397,12 @@ int idahip_set_lu_superpanel(idahip_ctx* c, int on) {
     return 0;
 }
 int idahip_lu_superpanel(const idahip_ctx* c) { return c ? c->lu_superpanel : -1; }
+int idahip_set_lu_period(idahip_ctx* c, int rounds) {
+    if (!c || rounds < 1 || rounds > 64) return -1;
+    c->lu_period = rounds;
+    return 0;
+}
+int idahip_lu_period(const idahip_ctx* c) { return c ? c->lu_period : -1; }
 
 // LSolver::get_type / num_iters / res_norm of the dense direct solver (crates/linear/src/dense.rs:30-36, traits.rs:82-90)
 int idahip_ls_type(const idahip_ctx* c) { return c ? IDAHIP_LS_DIRECT : -1; }

@@ -32,6 +32,7 @@ struct RoundArgs {
     long long round;        // index of this round within the call
     int first_round;        // systems enter the call in this round
     int fused_jac;          // the problem has a fused residual + Jacobian kernel (linear dense); otherwise two launches serve a setup
+    int lu_period;          // idahip_set_lu_period: > 1 = a round may postpone its linear setups (round_lists_kernel), at most lu_period - 1 rounds in a row
     // per-system round state (device arrays of length batch)
     int* stepping;          // the system takes step attempts
     int* in_newton;         // the system's Newton solve is under way in this round
@@ -42,6 +43,7 @@ struct RoundArgs {
     int* ident;             // 0, 1, 2, ...: the kernels' index list
     int* lu_list;           // systems to factor
     int* lu_cnt;            // [1]
+    int* lu_wait;           // [1] rounds in a row that have postponed their setups
     const int* lu_info;     // [batch] zero-pivot flags of the last factorisation
     double* tn;             // [batch] arguments of the residual kernels
     double* cj;
@@ -267,26 +269,59 @@ __global__ __launch_bounds__(WG_NT) void round_begin_kernel(RoundArgs a) {
         a.tn[b] = s.tn;
         a.cj[b] = s.cj;
         if (kind != 0) a.rounds_done[b] += 1;
-        if (kind == 1) atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
-        if (kind == 2) {
-            if (a.fused_jac) {
-                atomicAdd(&a.stats[IDAHIP_K_SYS_JAC], 1ull);
-            } else {
-                atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);
-                atomicAdd(&a.stats[IDAHIP_K_JAC], 1ull);
-            }
-            atomicAdd(&a.stats[IDAHIP_K_LU], 1ull);
-        }
+        if (kind == 1) atomicAdd(&a.stats[IDAHIP_K_SYS], 1ull);  // (kind 2: counted by round_lists_kernel, once the round's setups are decided)
     }
 }
 
 // ---- the list of systems to factor (ascending system id) and its length; one workgroup of 1024 threads
+// Setups batched over rounds (idahip_set_lu_period(k), k > 1): a batched factorisation of matrices with thousands of rows costs about
+// the same for 50 matrices as for 250 (a workgroup per matrix, a long chain of launches), and in a stream of integrations a third
+// of the systems ask for one in any round. This kernel counts the systems whose attempt calls for a setup and the systems that
+// step at all; unless the former are at least (k - 1) / k of the latter, or k - 1 rounds in a row have waited already, the round
+// sets nothing up: those systems take no part in it -- their attempts begun, their predictions made, in the state of a system
+// whose Newton solve starts over with a setup (newton_retry; call_lsetup is set either way: round_begin_kernel) -- and ask again
+// next round, while the others go on stepping. Which round a system's attempt runs in is the scheduler's business: its
+// arithmetic, its counters and its results do not change (tests/test_gpu_device_controller.py).
 __global__ __launch_bounds__(1024) void round_lists_kernel(RoundArgs a) {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
+    __shared__ int s_wave[16], s_wave2[16];
+    __shared__ int s_base, s_hold;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_base = 0;
+    if (t == 0) { s_base = 0; s_hold = 0; }
     __syncthreads();
+    if (a.lu_period > 1) {
+        int want = 0, step = 0;
+        for (int b = t; b < a.f.batch; b += 1024) {
+            want += a.skipL[b] == 0 ? 1 : 0;
+            step += a.stepping[b] != 0 ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            want += __shfl_xor(want, o);
+            step += __shfl_xor(step, o);
+        }
+        if (lane == 0) { s_wave[wave] = want; s_wave2[wave] = step; }
+        __syncthreads();
+        if (t == 0) {
+            int w = 0, st = 0;
+            for (int q = 0; q < 16; ++q) { w += s_wave[q]; st += s_wave2[q]; }
+            const int waited = a.lu_wait[0];
+            const bool hold = w > 0 && (long)w * a.lu_period < (long)st * (a.lu_period - 1) && waited < a.lu_period - 1;
+            s_hold = hold ? 1 : 0;
+            a.lu_wait[0] = hold ? waited + 1 : 0;
+        }
+        __syncthreads();
+        if (s_hold) {
+            for (int b = t; b < a.f.batch; b += 1024)
+                if (a.skipL[b] == 0) {
+                    a.sys[b].newton_retry = true;
+                    a.in_newton[b] = 0;
+                    a.skipL[b] = 1;
+                    a.rounds_done[b] -= 1;
+                }
+            if (t == 0) a.lu_cnt[0] = 0;
+            return;
+        }
+        __syncthreads();
+    }
     for (int b0 = 0; b0 < a.f.batch; b0 += 1024) {
         const int b = b0 + t;
         const bool in = b < a.f.batch && a.skipL[b] == 0;
@@ -304,7 +339,19 @@ __global__ __launch_bounds__(1024) void round_lists_kernel(RoundArgs a) {
         }
         __syncthreads();
     }
-    if (t == 0) a.lu_cnt[0] = s_base;
+    if (t == 0) {
+        a.lu_cnt[0] = s_base;
+        const unsigned long long cnt = (unsigned long long)s_base;  // the per-class statistics of the systems that set up in this round
+        if (cnt) {
+            if (a.fused_jac) {
+                atomicAdd(&a.stats[IDAHIP_K_SYS_JAC], cnt);
+            } else {
+                atomicAdd(&a.stats[IDAHIP_K_SYS], cnt);
+                atomicAdd(&a.stats[IDAHIP_K_JAC], cnt);
+            }
+            atomicAdd(&a.stats[IDAHIP_K_LU], cnt);
+        }
+    }
 }
 
 // ---- Newton's bookkeeping between the batched kernels (newton.rs:73-153, ida_nls.rs:168-179, 218-266); one thread per system.
@@ -399,6 +446,7 @@ __global__ __launch_bounds__(WG_NT) void round_end_kernel(RoundArgs a) {
 
 __global__ void round_init_kernel(RoundArgs a) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) a.lu_wait[0] = 0;
     if (b >= a.f.batch) return;
     a.ident[b] = b;
     a.stepping[b] = 0;

@@ -37,7 +37,7 @@ HIP_SYMBOLS = [
     "idahip_predict", "idahip_post_newton", "idahip_restore", "idahip_complete_step", "idahip_get_solution", "idahip_get_dky",
     "idahip_timing_enable", "idahip_timing_get", "idahip_timing_reset", "idahip_set_lu_variant", "idahip_snapshot_initial",
     "idahip_tiny_solve", "idahip_pow_batch", "idahip_round_solve", "idahip_lu_variant",
-    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams", "idahip_stream_pair_share", "idahip_set_lu_superpanel", "idahip_lu_superpanel",
+    "idahip_restore_initial", "idahip_ls_type", "idahip_ls_num_iters", "idahip_ls_res_norm", "idahip_timing_build", "idahip_concurrent_streams", "idahip_release_streams", "idahip_stream_pair_share", "idahip_set_lu_superpanel", "idahip_lu_superpanel", "idahip_set_lu_period", "idahip_lu_period",
 ]
 ENS_SYMBOLS = [
     "idaens_create", "idaens_destroy", "idaens_last_error", "idaens_set_max_num_steps", "idaens_set_max_ord", "idaens_set_fused_newton", "idaens_set_device_controller", "idaens_device_controller_active", "idaens_set_roots", "idaens_set_root_fn",
@@ -84,6 +84,8 @@ def load():
     H.idahip_stream_pair_share.argtypes = [ci, vp, vp, C.POINTER(cd)]
     H.idahip_set_lu_superpanel.argtypes = [vp, ci]
     H.idahip_lu_superpanel.argtypes = [vp]
+    H.idahip_set_lu_period.argtypes = [vp, ci]
+    H.idahip_lu_period.argtypes = [vp]
     H.idahip_last_error.argtypes = [vp]
     H.idahip_last_error.restype = C.c_char_p
     H.idahip_sync.argtypes = [vp]
@@ -405,6 +407,13 @@ class Ctx:
 
     def lu_superpanel(self):
         return int(self.H.idahip_lu_superpanel(self.h))
+
+    def set_lu_period(self, rounds):
+        """Device lock-step stepper: a round postpones its linear setups unless (k - 1) / k of the stepping systems ask for one, at most k - 1 rounds in a row (results unchanged)."""
+        self._chk(self.H.idahip_set_lu_period(self.h, int(rounds)), "set_lu_period")
+
+    def lu_period(self):
+        return int(self.H.idahip_lu_period(self.h))
 
     def set_lu_variant(self, variant):
         self._chk(self.H.idahip_set_lu_variant(self.h, int(variant)), "set_lu_variant")

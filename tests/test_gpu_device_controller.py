@@ -292,6 +292,48 @@ def test_device_lock_step_rounds_for_the_heat_problem(n, batch, ntout):
     assert dev.total_rounds() >= host.total_rounds() > 0
 
 
+@pytest.mark.parametrize("kind,n,batch,ntout,period", [("heat1d", 1100, 6, 3, 3), ("heat1d", 40, 9, 10, 4), ("linear_dense", 200, 12, 10, 2),
+                                                      ("linear_dense", 64, 16, 10, 5)])
+def test_factorisations_batched_over_rounds_change_no_result(kind, n, batch, ntout, period):
+    """idahip_set_lu_period(k): a lock-step round postpones its linear setups unless (k - 1) / k of the stepping systems ask for one
+    (at most k - 1 rounds in a row); a system whose attempt calls for one waits, its attempt begun, while the others go on. Every system performs the same attempts with the same arithmetic: state, step
+    sizes, orders and every counter at every output equal those of the unbatched run (and so the oracle's: the test above);
+    only the number of rounds grows. Also across round-limited calls, which can leave a waiting system to the next call, and
+    with the host stepper taking over a waiting system (it treats it like a Newton solve that starts over with a setup)."""
+    from idahip import problems
+    prob = problems.heat1d(n=n, batch=batch) if kind == "heat1d" else problems.linear_dense(n=n, batch=batch, procs=1)
+    touts = [float(t) for t in prob["touts"][:ntout]]
+    c1, plain = make(prob, 1)
+    ck, held = make(prob, 1)
+    assert ck.lu_period() == 1
+    ck.set_lu_period(period)
+    assert ck.lu_period() == period
+    for t in touts:
+        s1, t1 = plain.solve(t)
+        sk, tk = held.solve(t)
+        assert (s1 == 0).all() and np.array_equal(s1, sk) and np.array_equal(t1, tk)
+        same(state(plain), state(held))
+    assert held.total_rounds() >= plain.total_rounds() > 0
+    print("rounds: %d unbatched, %d with period %d" % (plain.total_rounds(), held.total_rounds(), period))
+    # round-limited calls (a waiting system is handed to the next call), every third call on the host stepper
+    cm, mix = make(prob, 1)
+    cm.set_lu_period(period)
+    ym = np.full((len(touts), batch, n), np.nan)
+    for i in range(20000):
+        on_device = i % 3 != 2
+        mix.set_device_controller(1 if on_device else 0)
+        s, t, r, yo, ypo = mix.solve_schedule(touts, max_rounds=2, outputs=True)
+        m = ~np.isnan(yo)
+        ym[m] = yo[m]
+        if (s != 99).all():
+            break
+    assert (s == 0).all()
+    same(state(mix), state(plain))
+    c2, sched = make(prob, 1)
+    s, t, r, yo, ypo = sched.solve_schedule(touts, outputs=True)
+    assert (s == 0).all() and np.array_equal(ym, yo)
+
+
 def test_heat_stream_beyond_1024_rows_on_both_steppers():
     """Throughput mode for n > 1024 on the device lock-step stepper: there the round's LU-list length travels to the host (behind
     the residual kernels) to size the factorisation's launches, also when the rounds are enqueued without any other
