@@ -29,6 +29,7 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     w.mats = work; w.mstride = wstride; w.idx = d_idx; w.cnt = d_cnt; w.n = n;
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;
     w.zmap = (out == c->lu) ? c->lu_zmap : nullptr;  // the map describes the ctx's own factors (the Newton iteration's solves)
+    w.dirty = (out == c->lu) ? c->lu_dirty : nullptr;  // (nothing else ever writes the ctx's own factors for n >= 2048)
     w.l11 = c->lu_l11; w.stamps = c->dbg_stamps; w.out = out; w.ostride = ostride; w.l11ld = 64;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;

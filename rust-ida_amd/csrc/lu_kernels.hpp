@@ -48,6 +48,7 @@ struct LuWs {
     int* nzb;          // [batch]   lu_trail64w_kernel, n > 1024: column blocks of the first super-panel's update that had work
     int* bz;           // [batch][64] n > 1024: per column block of the current super-panel's update, 1 = its pivot rows have a non-zero entry
     unsigned char* zmap;  // null, or [batch][64][64] (n >= 2048): zmap[K][I] = 1 when block (rows I, columns K) of the factors may be non-zero
+    unsigned char* dirty; // null, or [batch][64][64] with zmap: dirty[K][I] = 1 once block (rows I, columns K) of `out` has held a value with non-zero bits; never reset
     int* redo;         // [batch]   lu_wavepanel_kernel: 0 | 1 + first 8-column block of the super-panel left to its SLOW launch
     double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
     int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
@@ -608,26 +609,32 @@ __global__ __launch_bounds__(256) void lu_u12_zero_kernel(LuWs w, int k0, int ns
     const int cb0 = k0 + 64 + cbi * 64;
     const int ncols = (n - cb0) < 64 ? (n - cb0) : 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __shared__ int s_nz[4];
+    __shared__ int s_nz[4], s_bits[4];
     const int pr = w.prow[(long)b * n + k0 + lane];
     double g[16];
-    bool nz = false;
+    bool nz = false, bits = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int cc = wave * 16 + i;
         g[i] = A[(long)(cb0 + (cc < ncols ? cc : 0)) * n + pr];
         nz = nz || (cc < ncols && g[i] != 0.0);
+        bits = bits || (cc < ncols && __double_as_longlong(g[i]) != 0ll);  // (a -0.0 is content)
     }
-    const bool wnz = __ballot(nz) != 0ull;
-    if (lane == 0) s_nz[wave] = wnz ? 1 : 0;
+    const bool wnz = __ballot(nz) != 0ull, wbits = __ballot(bits) != 0ull;
+    if (lane == 0) { s_nz[wave] = wnz ? 1 : 0; s_bits[wave] = wbits ? 1 : 0; }
     __syncthreads();
     const int any = s_nz[0] | s_nz[1] | s_nz[2] | s_nz[3];
+    const int anyb = s_bits[0] | s_bits[1] | s_bits[2] | s_bits[3];
+    const long blk = (long)b * 4096 + ((k0 >> 6) + 1 + cbi) * 64 + (k0 >> 6);  // U block (rows k0 / 64, these columns)
     if (t == 0) {
         w.bz[b * 64 + cbi] = any;
         if (any && k0 == 0) atomicAdd(w.nzb + b, 1);
-        if (any && w.zmap) w.zmap[(long)b * 4096 + ((k0 >> 6) + 1 + cbi) * 64 + (k0 >> 6)] = 1;  // U block (rows k0 / 64, these columns)
+        if (any && w.zmap) w.zmap[blk] = 1;
+        if (anyb && w.dirty) w.dirty[blk] = 1;  // (`any`: lu_trail64w_kernel will write this block's U12)
     }
     if (any) return;
+    // all-zero-bits rows bound for a block of the ctx's factors that has only ever held zeros are there already (lu_finalize_kernel)
+    if (w.dirty && !anyb && w.dirty[blk] == 0) return;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int cc = wave * 16 + i;
@@ -1402,7 +1409,33 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
             const int spend = (p / w_ + 1) * w_;  // first column right of the panel that made row p a pivot row
             je = je < spend ? je : spend;
         }
-        if (w.zmap) {  // the same copy, noting which 64 x 64 blocks of the factors receive a non-zero (or a NaN)
+        if (w.zmap && w.dirty) {
+            // The same copy, noting which 64 x 64 blocks of the factors receive a non-zero (or a NaN) -- and without writing +0.0 over
+            // +0.0: the ctx's factors start as zeros, `dirty` marks the blocks that have ever received a value with non-zero bits
+            // (a -0.0 multiplier counts), and an all-zero-bits value bound for a block that never has is there already. For a banded
+            // matrix in dense storage that is nearly every entry of L: the scatter reads the lower triangle and writes the band.
+            unsigned char* __restrict__ zm = w.zmap + (long)b * 4096;
+            unsigned char* __restrict__ dm = w.dirty + (long)b * 4096;
+            // (a workgroup's columns lie in one 64-column block -- cols_per_block divides 64 --, so a row meets one block: one look
+            // at the maps per row, not per entry)
+            const int blk = (jbeg >> 6) * 64 + (p >> 6);
+            const bool was_dirty = dm[blk] != 0;
+            bool anybits = false, anynz = false;
+            for (int j0 = jbeg; j0 < je; j0 += 8) {  // eight columns' loads in flight per thread (the trip count differs from row to row: the compiler does not unroll it)
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (j0 + u < je) ? A[(long)(j0 + u) * n + r] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool bits = __double_as_longlong(v[u]) != 0ll;  // (a column beyond je: +0.0, no bits, no store when the block is clean; and never stored: see the test on j)
+                    anybits = anybits || bits;
+                    anynz = anynz || (v[u] != 0.0);
+                    if (j0 + u < je && (bits || was_dirty)) O[(long)(j0 + u) * n + p] = v[u];
+                }
+            }
+            if (anybits && !was_dirty) dm[blk] = 1;
+            if (anynz) zm[blk] = 1;
+        } else if (w.zmap) {  // the same copy, noting which 64 x 64 blocks of the factors receive a non-zero (or a NaN)
             unsigned char* __restrict__ zm = w.zmap + (long)b * 4096;
             for (int j = jbeg; j < je; ++j) {
                 const double v = A[(long)j * n + r];

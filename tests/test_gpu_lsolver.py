@@ -275,6 +275,53 @@ def test_nan_infinity_zero_pivot_and_ties_beyond_1024_rows(large_n_pipeline):
     assert np.array_equal(lu[ok], lu_o[ok], equal_nan=True)
 
 
+def test_ctx_factors_stay_exact_when_the_structure_changes_between_setups():
+    """n >= 2048: the row scatter into the ctx's own factors does not write all-zero-bits values into 64 x 64 blocks that have only ever
+    held zeros (lu_finalize_kernel, LuWs::dirty: the buffer starts as zeros and the map never resets). Successive setups on ONE ctx
+    with changing structure -- a row-permuted band whose multipliers sit far from the diagonal, then a plain tridiagonal matrix
+    (the far entries must be cleared again), then a dense one, then a band again -- each bit-identical to the oracle, the solve too."""
+    import idahip
+    if LU_VARIANT != 4:
+        pytest.skip("one pipeline is enough for the scatter")
+    n, B = 2048, 2
+    rng = np.random.default_rng(20480)
+    i = np.arange(n)
+
+    def tri():
+        m = np.zeros((n, n))
+        m[i, i] = 4.0 + rng.random(n)
+        m[i[1:], i[:-1]] = -1.0 - rng.random(n - 1)
+        m[i[:-1], i[1:]] = -1.0 - rng.random(n - 1)
+        return m
+
+    def permuted_band():
+        m = tri()
+        p = np.arange(n)
+        blk = rng.permutation(n // 64)           # whole 64-row groups trade places: pivoting brings them back, L reaches far
+        p = (blk[:, None] * 64 + np.arange(64)[None, :]).ravel()
+        return m[p]
+
+    seq = [np.array([permuted_band(), tri()]), np.array([tri(), tri()]), rng.standard_normal((B, n, n)),
+           np.array([tri(), permuted_band()])]
+    ctx = idahip.Ctx("linear_dense", n, B)
+    ctx.set_lu_variant(LU_VARIANT)
+    zeros = np.zeros((B, n))
+    cj = 3.25
+    for step, Bm in enumerate(seq):
+        A = np.array([np.eye(n) * 0.5 for _ in range(B)])
+        ctx.set_linear_dense(colmajor(A), colmajor(Bm), zeros)
+        rc, info = ctx.nls_lsetup(0.0, cj)
+        assert rc == 0 and not info.any(), step
+        for s_ in range(B):
+            J = Bm[s_] + cj * A[s_]
+            info_o, lu_o, piv_o = O.getrf(J)
+            lu, piv = ctx.download_lu(s_)
+            assert info_o == 0 and np.array_equal(piv, piv_o), (step, s_)
+            assert np.array_equal(lu, lu_o), (step, s_)
+            assert np.array_equal(np.signbit(lu), np.signbit(lu_o)), (step, s_)  # zeros with their signs: the map counts a -0.0 as content
+    ctx.close()
+
+
 def test_pivot_ties_resolve_like_the_reference_scan():
     n = 40
     rng = np.random.default_rng(7)
