@@ -237,6 +237,20 @@ impl Ctx {
         let rc = unsafe { sys::idahip_set_lu_variant(self.raw, variant) };
         self.check(rc).map(|_| ())
     }
+
+    /// n > 1024: a 64-column super-panel in one launch (banded Jacobians) or panel by panel (dense ones); results identical.
+    pub fn set_lu_superpanel(&mut self, on: bool) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_set_lu_superpanel(self.raw, on as i32) };
+        self.check(rc).map(|_| ())
+    }
+
+    /// Device lock-step stepper: linear setups batched over rounds. With `rounds` = k > 1 a round postpones its setups unless
+    /// (k - 1) / k of the stepping systems ask for one, at most k - 1 rounds in a row; results identical (a scheduling choice
+    /// for ensembles whose factorisations are latency bound).
+    pub fn set_lu_period(&mut self, rounds: i32) -> Result<(), Error> {
+        let rc = unsafe { sys::idahip_set_lu_period(self.raw, rounds) };
+        self.check(rc).map(|_| ())
+    }
 }
 
 impl Drop for Ctx {
