@@ -63,6 +63,7 @@ struct idahip_ctx {
     int32_t* perm = nullptr; // [batch][n]  composed row permutation: b_perm[i] = b[perm[i]]
     // blocked-LU workspace
     int32_t *lu_pos = nullptr, *lu_live = nullptr, *lu_prow = nullptr, *lu_info = nullptr, *lu_redo = nullptr, *lu_nzb = nullptr, *lu_bz = nullptr;
+    int32_t* lu_jwzero = nullptr; // [batch], n >= 2048: 1 = the last factorisation has left the system's work matrix (jw) all +0.0 (LuWs::jwzero)
     uint8_t* lu_dirty = nullptr; // [batch][64][64], n >= 2048: [K][I] = 1 once the 64 x 64 block (rows I, columns K) of `lu` has received a value with non-zero bits (never reset: `lu` starts as zeros and lu_finalize_kernel does not rewrite zeros into blocks that have only ever held zeros)
     uint8_t* lu_zmap = nullptr;  // [batch][64][64], n >= 2048: [K][I] = 1 when the 64 x 64 block (rows I, columns K) of the factors in `lu` may hold a non-zero
     double* lu_l11 = nullptr;

@@ -107,6 +107,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (n > LU_MAX_N) rc |= dalloc(c, &c->lu_bz, (size_t)batch * 64);
     if (n >= LU_ZMAP_MIN_N) rc |= dalloc(c, &c->lu_zmap, (size_t)batch * 4096);
     if (n >= LU_ZMAP_MIN_N) rc |= dalloc(c, &c->lu_dirty, (size_t)batch * 4096);
+    if (n >= LU_ZMAP_MIN_N) rc |= dalloc(c, &c->lu_jwzero, (size_t)batch);
     if (n > TINY_N) {
         rc |= dalloc(c, &c->jw, bnn);
         rc |= dalloc(c, &c->lu_pos, bn); rc |= dalloc(c, &c->lu_live, bn); rc |= dalloc(c, &c->lu_prow, bn);
@@ -141,6 +142,7 @@ int idahip_create(idahip_ctx** out, int device, int n, int batch, idahip_problem
     if (c->lu_dirty) {  // the factors start as zeros, and so does the map of their blocks that have ever held anything else
         (void)hipMemsetAsync(c->lu, 0, bnn * sizeof(double), c->stream);
         (void)hipMemsetAsync(c->lu_dirty, 0, (size_t)batch * 4096, c->stream);
+        (void)hipMemsetAsync(c->lu_jwzero, 0, (size_t)batch * sizeof(int), c->stream);
     }
     (void)hipStreamSynchronize(c->stream);
     *out = c;
@@ -152,7 +154,7 @@ int idahip_destroy(idahip_ctx* c) {
     if (!c) return 0;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->yy, c->yp, c->yypredict, c->yppredict, c->ewt, c->ee, c->delta, c->savres, c->phi, c->lu, c->jw, c->piv, c->perm,
-                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_dirty, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
+                    c->lu_pos, c->lu_live, c->lu_prow, c->lu_info, c->lu_redo, c->lu_nzb, c->lu_bz, c->lu_zmap, c->lu_dirty, c->lu_jwzero, c->lu_l11, c->params, c->A, c->B, c->C, c->d_atol_v, c->ic_y,
                     c->ic_yp, c->dky, c->cb_stage, c->tiny_sys, c->tiny_touts, c->tiny_yout, c->tiny_ypout, c->tiny_start, c->tiny_rounds,
                     c->tiny_acc, c->tiny_roots, c->rnd_i, c->rnd_d};
     for (void* p : ptrs)
@@ -640,7 +642,8 @@ int launch_jac(idahip_ctx* c, double* work, const int* d_idx, const double* d_cj
         case IDAHIP_HEAT1D: {
             int chunks = 1;
             while ((long)nsys * chunks < 2048 && chunks < n) chunks *= 2;
-            hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks, d_skip);
+            hipLaunchKernelGGL(heat_jac_kernel, dim3(nsys, chunks), dim3(256), 0, c->stream, work, n, (const double*)c->params, d_idx, d_cj, chunks, d_skip,
+                               (work == c->jw) ? (const int*)c->lu_jwzero : nullptr);
             break;
         }
     }

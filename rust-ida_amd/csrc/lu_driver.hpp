@@ -30,6 +30,11 @@ inline int lu_factor_batched(idahip_ctx* c, double* work, long wstride, double* 
     w.pos = c->lu_pos; w.live = c->lu_live; w.prow = c->lu_prow; w.piv = piv; w.pstride = pstride; w.info = c->lu_info; w.redo = c->lu_redo; w.nzb = c->lu_nzb; w.bz = c->lu_bz;
     w.zmap = (out == c->lu) ? c->lu_zmap : nullptr;  // the map describes the ctx's own factors (the Newton iteration's solves)
     w.dirty = (out == c->lu) ? c->lu_dirty : nullptr;  // (nothing else ever writes the ctx's own factors for n >= 2048)
+    // the work matrix left all +0.0 for the next Jacobian (heat_jac_kernel): only where every super-panel is 64 columns wide -- the
+    // scatter's regions are then whole blocks of `dirty` -- and the matrices factored are the ctx's own work matrices
+    w.jwzero = (w.dirty && work == c->jw && c->lu_superpanel && n > LU_MAX_N) ? c->lu_jwzero : nullptr;
+    if (!w.jwzero && c->lu_jwzero && (work == c->jw || out == c->jw))  // the work matrix is about to hold something this flag does not describe
+        (void)hipMemsetAsync(c->lu_jwzero, 0, (size_t)c->batch * sizeof(int), c->stream);
     w.l11 = c->lu_l11; w.stamps = c->dbg_stamps; w.out = out; w.ostride = ostride; w.l11ld = 64;
     hipLaunchKernelGGL(lu_init_kernel, dim3(nsys), dim3(256), 0, c->stream, w);
     const int nsys8 = ((nsys + 7) / 8) * 8;

@@ -49,6 +49,9 @@ struct LuWs {
     int* bz;           // [batch][64] n > 1024: per column block of the current super-panel's update, 1 = its pivot rows have a non-zero entry
     unsigned char* zmap;  // null, or [batch][64][64] (n >= 2048): zmap[K][I] = 1 when block (rows I, columns K) of the factors may be non-zero
     unsigned char* dirty; // null, or [batch][64][64] with zmap: dirty[K][I] = 1 once block (rows I, columns K) of `out` has held a value with non-zero bits; never reset
+    int* jwzero;       // null, or [batch] (with dirty, work == the ctx's work matrix, every super-panel 64 columns wide): 1 = the factorisation has left the
+                       // work matrix all +0.0 (lu_finalize_kernel clears what it reads and the pivot rows' entries right of their super-panel); heat_jac_kernel
+                       // then writes the band only. lu_init_kernel resets it, lu_finalize_kernel sets it.
     int* redo;         // [batch]   lu_wavepanel_kernel: 0 | 1 + first 8-column block of the super-panel left to its SLOW launch
     double* l11;       // [batch][L11_STRIDE] transposed L11: l11[kk*l11ld + k] = multiplier of the k-th pivot row for column kk
     int l11ld;         // row length of l11: the (super-)panel width, 32 or 64
@@ -68,6 +71,7 @@ __global__ void lu_init_kernel(LuWs w) {
     if (threadIdx.x == 0) {
         w.info[b] = 0;
         w.nzb[b] = 0;
+        if (w.jwzero) w.jwzero[b] = 0;
     }
     if (w.zmap)
         for (int i = threadIdx.x; i < 4096 / 8; i += blockDim.x) reinterpret_cast<unsigned long long*>(w.zmap + (long)b * 4096)[i] = 0ull;
@@ -1391,10 +1395,12 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
     const int b = w.idx[blockIdx.x];
     if (w.info[b] != 0) return;
     const int n = w.n;
-    const double* __restrict__ A = w.mats + (long)b * w.mstride;
+    double* __restrict__ A = w.mats + (long)b * w.mstride;  // (read; with jwzero also cleared)
     double* __restrict__ O = out + (long)b * ostride;
     const int* __restrict__ pos = w.pos + (long)b * n;
     const int jbeg = blockIdx.y * cols_per_block;
+    const bool clearw = w.jwzero != nullptr && w.dirty != nullptr;
+    if (clearw && blockIdx.y == 0 && threadIdx.x == 0) w.jwzero[b] = 1;  // (read by kernels launched after this one)
     const int jend = (jbeg + cols_per_block < n) ? jbeg + cols_per_block : n;
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         const int p = pos[r];
@@ -1421,6 +1427,7 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
             const int blk = (jbeg >> 6) * 64 + (p >> 6);
             const bool was_dirty = dm[blk] != 0;
             bool anybits = false, anynz = false;
+            unsigned cmask = 0u;  // columns of this chunk (at most 32) in which the row had content
             for (int j0 = jbeg; j0 < je; j0 += 8) {  // eight columns' loads in flight per thread (the trip count differs from row to row: the compiler does not unroll it)
                 double v[8];
 #pragma unroll
@@ -1431,10 +1438,19 @@ __global__ __launch_bounds__(256) void lu_finalize_kernel(LuWs w, double* __rest
                     anybits = anybits || bits;
                     anynz = anynz || (v[u] != 0.0);
                     if (j0 + u < je && (bits || was_dirty)) O[(long)(j0 + u) * n + p] = v[u];
+                    if (bits && j0 + u < je) cmask |= 1u << (j0 + u - jbeg);
                 }
             }
             if (anybits && !was_dirty) dm[blk] = 1;
             if (anynz) zm[blk] = 1;
+            // jwzero: what was read has been read for the last time -- cleared after the loop (stores into the work matrix inside it would
+            // order every group of loads behind the stores of the group before)
+            if (clearw)
+                for (unsigned m = cmask; m != 0u; m &= m - 1u) A[(long)(jbeg + __builtin_ctz(m)) * n + r] = 0.0;
+            // The rest of the work matrix's content: a pivot row's entries right of its super-panel (what U12 was solved from). They lie
+            // in blocks that lu_u12_zero_kernel marked in `dirty` from these very values; cleared blind, a row of a marked block at a time.
+            if (clearw && je <= jbeg && dm[blk] != 0)
+                for (int j = jbeg; j < jend; ++j) A[(long)j * n + r] = 0.0;
         } else if (w.zmap) {  // the same copy, noting which 64 x 64 blocks of the factors receive a non-zero (or a NaN)
             unsigned char* __restrict__ zm = w.zmap + (long)b * 4096;
             for (int j = jbeg; j < je; ++j) {

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void heat_sys_kernel(SysArgs a, const double* 
 
 __global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats, int n, const double* __restrict__ params,
                                                        const int* __restrict__ idx, const double* __restrict__ cjs, int chunks,
-                                                       const int* __restrict__ skip) {
+                                                       const int* __restrict__ skip, const int* __restrict__ zeroed) {
     if (skip && skip[blockIdx.x] != 0) return;  // (the device lock-step stepper's per-system flags)
     const int b = idx[blockIdx.x];
     const double cj = cjs[blockIdx.x];
@@ -273,6 +273,23 @@ __global__ __launch_bounds__(256) void heat_jac_kernel(double* __restrict__ mats
     const int per = (n + chunks - 1) / chunks;  // columns per block
     const int jbeg = blockIdx.y * per;
     const int jend = (jbeg + per < n) ? jbeg + per : n;
+    if (zeroed && zeroed[b] != 0) {
+        // the last factorisation has left this system's matrix all +0.0 (LuWs::jwzero): J <- 0 (ida_ls.rs:254) is in place already, the
+        // band is all there is to write -- 3 entries of a column instead of n
+        for (int j = jbeg + threadIdx.x; j < jend; j += 256) {
+            for (int i = (j > 0 ? j - 1 : 0); i <= j + 1 && i < n; ++i) {
+                double v = 0.0;
+                if (i == 0 || i == n - 1) {
+                    v = (j == i) ? 1.0 : 0.0;
+                } else {
+                    if (j == i) v = cj + 2.0 * coef;
+                    else v = -coef;
+                }
+                J[(long)j * n + i] = v;
+            }
+        }
+        return;
+    }
     for (int j = jbeg; j < jend; ++j) {
         for (int i = threadIdx.x; i < n; i += 256) {
             double v = 0.0;
