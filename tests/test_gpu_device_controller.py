@@ -334,6 +334,33 @@ def test_factorisations_batched_over_rounds_change_no_result(kind, n, batch, nto
     assert (s == 0).all() and np.array_equal(ym, yo)
 
 
+@pytest.mark.parametrize("variant,superpanel", [(4, 1), (3, 1), (4, 0), (3, 0)])
+def test_heat_setups_on_a_work_matrix_the_factorisation_left_zeroed(variant, superpanel, monkeypatch):
+    """n >= 2048: with super-panel launches a factorisation leaves the ctx's work matrix all +0.0 (LuWs::jwzero) and the next
+    Jacobian of the heat problem writes its band only; with the panel-by-panel pipeline it does not and the Jacobian kernel
+    writes the whole matrix. Fourteen setups per system at n = 2120 on every pipeline combination, against the oracle."""
+    import idahip
+    from idahip import problems
+    monkeypatch.setenv("IDAHIP_LU_SUPERPANEL", str(superpanel))
+    prob = problems.heat1d(n=2120, batch=3)
+    touts = [float(t) for t in prob["touts"][:3]]
+    ctx = problems.make_ctx(prob)
+    ctx.set_lu_variant(variant)
+    assert ctx.lu_superpanel() == superpanel
+    ens = idahip.Ensemble(ctx, prob["yy0"], prob["yp0"])
+    ref = O.run_ensemble("heat1d", 2120, prob["yy0"], prob["yp0"], prob["rtol"], prob["atol"], touts, params=prob["params"], nthreads=3)
+    for i, t in enumerate(touts):
+        s, tr = ens.solve(t)
+        assert (s == 0).all()
+        assert np.array_equal(ens.yy(), ref["yy"][i]) and np.array_equal(ens.yp(), ref["yp"][i]), i
+    c = ens.counters()
+    for k in CNT:
+        assert np.array_equal(c[k], ref["counters"][k]), k
+    assert int(c["nsetups"].min()) >= 10
+    ens.close()
+    ctx.close()
+
+
 def test_heat_stream_beyond_1024_rows_on_both_steppers():
     """Throughput mode for n > 1024 on the device lock-step stepper: there the round's LU-list length travels to the host (behind
     the residual kernels) to size the factorisation's launches, also when the rounds are enqueued without any other
