@@ -18,14 +18,16 @@ What is timed.
                for it, 1..4 triangular solves + WRMS norms -> error test -> complete_step or restore, for every one of the B
                systems). value = Newton iterations of all systems on all ranks during the K timed steps / max over ranks of
                the wall time of those steps, inputs resident in HBM, NO event timers or extra synchronisation inside.
-  whole_pass   SURVEY 8(d)'s protocol next to it (N = 1 only): the whole ensemble from fresh state, t = 0 -> 1, median of 3
-               passes (Newton iterations of the pass / its wall time).
+  whole_pass   SURVEY 8(d)'s protocol next to it (N = 1 only): the whole ensemble from fresh state, t = 0 -> 1, median of 10
+               passes (--passes; Newton iterations of the pass / its wall time).
   kernel_classes_rank0, roofline, lu_plus_solve
                measured in further, untimed repetitions of the K steps with HIP-event timers on the ctx stream: once per
                kernel class, once per kernel of the LU (the dominant kernel's `roofline`).
   device_controller, newton_fusion  (N = 1 only) the whole pass again with the lock-step HOST stepper (idaens_set_device_controller(0))
                and, on top of that, with one host round trip per Newton iteration: the before/after of moving the controller to the
                device. Same work, same results.
+Scheduling (results do not depend on either): the rank's systems run as --groups ensembles side by side on the device and a
+lock-step round may postpone its linear setups until most stepping systems ask for one (--lu-period, idahip_set_lu_period).
 Multi-GPU (config 5): the ensemble shards embarrassingly -- rank r integrates systems [4096 r, 4096 (r+1)); no data-path
 collective; the ranks meet over gloo on CPU tensors for the barrier and the max-over-ranks of the time (no RCCL).
 """
