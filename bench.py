@@ -377,7 +377,7 @@ def launch_ranks(n):
 DEFAULT_GROUPS = {"linear_dense": 4, "heat1d": 1, "lorenz63": 1}
 # linear setups only in every k-th lock-step round (idahip_set_lu_period; systems that need one wait, results unchanged): pays where a
 # batched factorisation costs about the same for 50 matrices as for 250 (config 4), costs where its time is proportional to the batch
-DEFAULT_LU_PERIOD = {"linear_dense": 2, "heat1d": 5, "lorenz63": 1}
+DEFAULT_LU_PERIOD = {"linear_dense": 1, "heat1d": 5, "lorenz63": 1}
 
 
 WORKLOADS = {
